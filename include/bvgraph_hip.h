@@ -1,0 +1,156 @@
+/*
+ * bvgraph_hip.h — C ABI of libbvgraph_hip.so: the MI355X (gfx950) BVGraph successor-list decoder.
+ *
+ * This is the drop-in boundary for ONE path of vigna/webgraph-big (reference paths relative to
+ * /root/reference, BVG = src/it/unimi/dsi/big/webgraph/BVGraph.java, IG = .../ImmutableGraph.java):
+ * the BVGraph decode half behind nodeIterator()/successors()/outdegree().  A JNI (or ctypes / C++)
+ * shim binds exactly these entry points; INTEGRATION.md shows the Java side.
+ *
+ * Conventions: every function returns 0 or a negative bvg_status; no exceptions / longjmp cross the
+ * boundary; all output buffers are caller-allocated host memory unless the name ends in _dev;
+ * functions on ONE handle are not re-entrant, different handles (incl. bvg_copy() flyweights) are
+ * (IG:187-197 threading contract).  There is no CPU fallback: without a gfx950 device every compute
+ * entry point fails with BVG_E_HIP.
+ */
+#ifndef BVGRAPH_HIP_H
+#define BVGRAPH_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVG_ABI_VERSION 1
+
+/* Status codes; each maps 1:1 to the exception class the reference throws at the cited line. */
+typedef enum bvg_status {
+    BVG_OK = 0,
+    BVG_E_ARG = -1,          /* IllegalArgumentException   BVG:823,863,1000,1128 (node out of range) */
+    BVG_E_STATE = -2,        /* IllegalStateException      BVG:701 (ref > window), BVG:832,1136 (no offsets) */
+    BVG_E_UNSUPPORTED = -3,  /* UnsupportedOperationException BVG:631,658,699,733,763,794,864 */
+    BVG_E_IO = -4,           /* IOException                BVG:1492-1497,1326 (class / version / flag / file) */
+    BVG_E_EOF = -5,          /* EOFException from the bit stream (record runs past the end of .graph) */
+    BVG_E_NOMEM = -6,        /* OutOfMemoryError (host or device) */
+    BVG_E_HIP = -7,          /* no gfx950 device / HIP runtime failure (no CPU fallback exists) */
+    BVG_E_CAPACITY = -8      /* caller's successor buffer too small; *n_succ holds the size needed */
+} bvg_status;
+
+/* Coding ids, CompressionFlags.java:26-44. */
+enum { BVG_DELTA = 1, BVG_GAMMA = 2, BVG_GOLOMB = 3, BVG_SKEWED_GOLOMB = 4, BVG_UNARY = 5, BVG_ZETA = 6, BVG_NIBBLE = 7 };
+
+/* load_mode of bvg_open, = offsetType of BVG:1479 (loadInternal). */
+enum { BVG_LOAD_OFFLINE = -1, BVG_LOAD_SEQUENTIAL = 0, BVG_LOAD_STANDARD = 1, BVG_LOAD_MAPPED = 2 };
+
+/* The keys of basename.properties that drive decoding (BVG:1495-1503) + the six coding selectors
+ * (setFlags, BVG:1281-1289; defaults BVG:527-542). */
+typedef struct bvg_params {
+    int64_t nodes;
+    int64_t arcs;                 /* -1 if the properties do not say */
+    int32_t window_size;          /* default 7  (BVG:455) */
+    int32_t max_ref_count;        /* default 3  (BVG:461) */
+    int32_t min_interval_length;  /* default 4  (BVG:467); 0 = NO_INTERVALS (BVG:379) */
+    int32_t zeta_k;               /* default 3  (BVG:473) */
+    int32_t outdegree_coding;     /* GAMMA | DELTA */
+    int32_t block_coding;         /* GAMMA | DELTA | UNARY (the decoder's switch, BVG:759-764) */
+    int32_t residual_coding;      /* ZETA | GAMMA | DELTA | GOLOMB | NIBBLE */
+    int32_t reference_coding;     /* UNARY | GAMMA | DELTA */
+    int32_t block_count_coding;   /* GAMMA | DELTA | UNARY */
+    int32_t offset_coding;        /* GAMMA | DELTA */
+} bvg_params;
+
+/* Result of a fused on-chip scan (the SpeedTest loop, test/SpeedTest.java:127-141, plus a checksum). */
+typedef struct bvg_scan_result {
+    uint64_t nodes;        /* nodes scanned */
+    uint64_t arcs;         /* sum of outdegrees */
+    uint64_t chk;          /* sum over arcs (x,y) of bvg_arc_mix(x + node_base, y + node_base) mod 2^64 */
+    uint64_t graph_bytes;  /* ALGORITHMIC bytes: compressed .graph bytes covering the scanned node range */
+    uint64_t index_bytes;  /* device index bytes the kernels read on top (offsets + block plan) */
+    double kernel_ms;      /* hipEvent time of the scan kernel(s) on the handle's stream */
+    uint32_t launches;     /* kernel launches issued (1 + slow-path relaunches) */
+    uint32_t slow_blocks;  /* node blocks that had to take the global-memory slow path */
+} bvg_scan_result;
+
+typedef struct bvg_graph bvg_graph;
+
+/* ---- load (replaces ImmutableGraph.load -> BVGraph.loadInternal, IG:674-713, BVG:1479-1574) ---- */
+
+void bvg_default_params(bvg_params* p);
+/* Parses the text of a .properties file (BVG:1479-1503; class check BVG:1491, version BVG:1496). */
+int bvg_parse_properties(const char* text, size_t len, bvg_params* out);
+/* Decodes the n+1 gamma/delta coded offset gaps of basename.offsets (readOffset BVG:627-633,
+ * OffsetsLongIterator BVG:870-898) into out[0..nodes]. Host-side, one-off at load (the reference
+ * builds an Elias-Fano list here, BVG:1556-1558). */
+int bvg_decode_offsets(const uint8_t* obytes, size_t nbytes, int64_t nodes, int coding, uint64_t* out);
+
+/* BVGraph.load / loadMapped / loadOffline / loadSequential(basename) (BVG:1345-1464).  Reads
+ * basename.properties/.graph[/.offsets], uploads to `device`.  BVG_LOAD_SEQUENTIAL / _OFFLINE need
+ * no .offsets file: the index is derived on the device by one sequential pass. */
+int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out);
+/* Same from host memory.  offsets: nodes+1 bit positions or NULL (derive on device). */
+int bvg_open_mem(const bvg_params* p, const uint8_t* graph, uint64_t nbytes, const uint64_t* offsets, int device, bvg_graph** out);
+/* Same from DEVICE memory already resident in HBM (buffers are adopted, not copied; they must stay
+ * alive until bvg_close and d_graph must be readable up to nbytes rounded up to 16 + 16 bytes). */
+int bvg_open_dev(const bvg_params* p, const void* d_graph, uint64_t nbytes, const void* d_offsets, int device, bvg_graph** out);
+/* BVGraph.copy() (BVG:553-578): flyweight sharing the immutable device data, with its own stream
+ * and workspace, usable from another thread. */
+int bvg_copy(const bvg_graph* g, bvg_graph** out);
+void bvg_close(bvg_graph* g);
+
+int bvg_info(const bvg_graph* g, bvg_params* out);           /* numNodes/numArcs/windowSize/... */
+/* The handle may stand for nodes [node_base, node_base + nodes) of a larger graph (a shard made by
+ * ImmutableGraph.splitNodeIterators, IG:405-436): node ids and successors reported by scan /
+ * decode are shifted by node_base.  Default 0. */
+int bvg_set_node_base(bvg_graph* g, uint64_t node_base);
+/* Copies the device offsets index back (nodes+1 entries): BVGraph -O / writeOffsets (BVG:2595-2609). */
+int bvg_get_offsets(bvg_graph* g, uint64_t* out);
+
+/* ---- decode (replaces BVG:821-867 outdegree/successors and BVG:1100-1245 BVGraphNodeIterator) ---- */
+
+/* outdegree(x) for x in [from,to) (BVG:821-842). */
+int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out);
+/* Materialises successors of nodes [from,to): outdeg[to-from] and the concatenated, strictly
+ * increasing successor lists in succ (bit-exact with nodeIterator(from)...successorBigArray()).
+ * to == from+1 is successors(x) (BVG:860-867).  If succ_cap is too small returns BVG_E_CAPACITY
+ * with *n_succ = required size (succ may be NULL to query).  outdeg may be NULL. */
+int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
+/* Same, successor / outdegree buffers in device memory (stay in HBM for a downstream kernel). */
+int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ);
+/* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum). */
+int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
+/* Node-range split points for k shards of ~equal compressed size (the balanced variant of
+ * IG:405-436; cf. algo/HyperBall.java:748-768): bounds[0..k], bounds[0]=0, bounds[k]=nodes. */
+int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);
+
+/* ---- synthetic-workload helper (bench only): K back-to-back copies of the graph ----
+ * BV records are translation invariant (every value is coded relative to the node id, Appendix A.3
+ * of SURVEY.md), so the concatenation of K copies of the bit stream is a valid BVGraph with K*nodes
+ * nodes in which copy j is the base graph shifted by j*nodes.  Built on the device. */
+int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out);
+
+/* ---- tuning knobs (optional) ---- */
+typedef struct bvg_tuning {
+    uint32_t block_bits;     /* target compressed bits per node block (one wavefront each); 0 = default */
+    uint32_t force_wide;     /* 1 = use the 64-bit successor kernels even when nodes < 2^31 */
+    uint32_t force_slow;     /* 1 = route every block through the global-memory slow path (tests) */
+    uint32_t reserved;
+} bvg_tuning;
+int bvg_set_tuning(bvg_graph* g, const bvg_tuning* t);
+
+const char* bvg_strerror(int status);
+int bvg_abi_version(void);
+
+/* ---- checksum definition (shared with the CPU oracle) ----
+ *   kx = splitmix64(x);  k0 = (u32)kx;  k1 = (u32)(kx >> 32) | 1
+ *   a  = (u32)y + k0 + (u32)(y >> 32) * 0x9E3779B1        (mod 2^32)
+ *   b  = a * 0x85EBCA6B (mod 2^32);  b ^= b >> 15
+ *   bvg_arc_mix(x, y) = (u64)b * (u64)k1
+ * chk = sum of bvg_arc_mix over all arcs, mod 2^64: commutative, so node-range shards reduce with
+ * a plain sum (one RCCL all-reduce of {arcs, chk}). */
+uint64_t bvg_arc_mix(uint64_t x, uint64_t y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVGRAPH_HIP_H */
