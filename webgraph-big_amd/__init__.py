@@ -1,2 +1,11 @@
-"""webgraph-big_amd — MI355X-native BVGraph successor-list decoding."""
+"""webgraph-big_amd — MI355X-native BVGraph successor-list decoding.
+
+The package holds only what the decode path needs: csrc/ (HIP kernels + C ABI), bvgraph.py (host-side
+mirror of the reference's ImmutableGraph / NodeIterator / LazyLongIterator API over the C ABI) and
+tools.py (CPU encoder + synthetic graphs, for tests and bench input generation only).
+"""
 from ._abi import *  # noqa: F401,F403
+from ._abi import Params, ScanResult, Tuning, default_params  # noqa: F401
+from .bvgraph import (BVGraph, NodeIterator, LazyLongIterator, BVGraphError, IllegalArgumentException,  # noqa: F401
+                      IllegalStateException, UnsupportedOperationException, IOException, EOFException, DeviceError,
+                      NoSuchElementException, parse_properties, decode_offsets, arc_mix, build, lib, library_path)

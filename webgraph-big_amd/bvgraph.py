@@ -1,0 +1,431 @@
+"""Host-side mirror of the reference's graph API over the C ABI of libbvgraph_hip.so.
+
+Class and method names follow the reference (paths relative to /root/reference/src/it/unimi/dsi/big/webgraph):
+  ImmutableGraph.java:245-447   numNodes / numArcs / randomAccess / outdegree / successors /
+                                successorBigArray / nodeIterator / splitNodeIterators / copy
+  NodeIterator.java:34-133      hasNext / nextLong / outdegree / successors / successorBigArray / copy(upperBound) / skip
+  LazyLongIterator.java:28-44   nextLong() returns -1 at the end; skip(n)
+  BVGraph.java:1345-1464        load / loadMapped / loadOffline / loadSequential
+
+Every decode goes through the HIP kernels (bvg_decode_range / bvg_scan); there is no CPU decode in
+this package and importing it on a box without the built library or without a GPU fails loudly at
+the first call that needs the device.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+from ._abi import Params, ScanResult, Tuning
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class BVGraphError(Exception):
+    """Base of the status-code exceptions; subclasses mirror the Java exception classes."""
+
+    def __init__(self, status, what=""):
+        self.status = status
+        msg = lib().bvg_strerror(status).decode() if _LIB is not None else str(status)
+        super().__init__("%s [%d] %s" % (what, status, msg))
+
+
+class IllegalArgumentException(BVGraphError, ValueError):
+    pass
+
+
+class IllegalStateException(BVGraphError, RuntimeError):
+    pass
+
+
+class UnsupportedOperationException(BVGraphError, NotImplementedError):
+    pass
+
+
+class IOException(BVGraphError, OSError):
+    pass
+
+
+class EOFException(IOException):
+    pass
+
+
+class DeviceError(BVGraphError):
+    pass
+
+
+class NoSuchElementException(StopIteration):
+    pass
+
+
+_EXC = {_abi.E_ARG: IllegalArgumentException, _abi.E_STATE: IllegalStateException, _abi.E_UNSUPPORTED: UnsupportedOperationException,
+        _abi.E_IO: IOException, _abi.E_EOF: EOFException, _abi.E_NOMEM: MemoryError, _abi.E_HIP: DeviceError}
+
+
+def _check(status, what=""):
+    if status == 0:
+        return
+    exc = _EXC.get(status, BVGraphError)
+    if exc is MemoryError:
+        raise MemoryError("%s: out of host/device memory" % what)
+    raise exc(status, what)
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "libbvgraph_hip.so")
+
+
+def build(force=False):
+    """Compiles libbvgraph_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    so = library_path()
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))] + [os.path.join(_HERE, "..", "include", "bvgraph_hip.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "lib/libbvgraph_hip.so"])
+    return so
+
+
+def lib():
+    """Loads the HIP library; raises if it is missing (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        so = library_path()
+        if not os.path.exists(so):
+            raise ImportError("libbvgraph_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
+        L = C.CDLL(so)
+        vp, i64, u64, pp = C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_void_p)
+        L.bvg_abi_version.restype = C.c_int
+        L.bvg_default_params.argtypes = [C.POINTER(Params)]
+        L.bvg_parse_properties.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Params)]
+        L.bvg_decode_offsets.argtypes = [vp, C.c_size_t, i64, C.c_int, vp]
+        L.bvg_open.argtypes = [C.c_char_p, C.c_int, C.c_int, pp]
+        L.bvg_open_mem.argtypes = [C.POINTER(Params), vp, u64, vp, C.c_int, pp]
+        L.bvg_open_dev.argtypes = [C.POINTER(Params), vp, u64, vp, C.c_int, pp]
+        L.bvg_copy.argtypes = [vp, pp]
+        L.bvg_close.argtypes = [vp]; L.bvg_close.restype = None
+        L.bvg_info.argtypes = [vp, C.POINTER(Params)]
+        L.bvg_set_node_base.argtypes = [vp, u64]
+        L.bvg_get_offsets.argtypes = [vp, vp]
+        L.bvg_outdegrees.argtypes = [vp, i64, i64, vp]
+        L.bvg_decode_range.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
+        L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
+        L.bvg_tile.argtypes = [vp, i64, pp]
+        L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
+        L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
+        L.bvg_arc_mix.argtypes = [u64, u64]; L.bvg_arc_mix.restype = u64
+        if L.bvg_abi_version() != 1:
+            raise ImportError("libbvgraph_hip.so ABI mismatch")
+        _LIB = L
+    return _LIB
+
+
+def parse_properties(text):
+    if isinstance(text, str):
+        text = text.encode()
+    p = Params()
+    _check(lib().bvg_parse_properties(text, len(text), C.byref(p)), "parse_properties")
+    return p
+
+
+def decode_offsets(obytes, nodes, coding=_abi.GAMMA):
+    buf = np.frombuffer(bytes(obytes), dtype=np.uint8)
+    out = np.empty(nodes + 1, dtype=np.uint64)
+    _check(lib().bvg_decode_offsets(buf.ctypes.data if len(buf) else None, len(buf), nodes, coding, out.ctypes.data), "decode_offsets")
+    return out
+
+
+def arc_mix(x, y):
+    return int(lib().bvg_arc_mix(x, y))
+
+
+class LazyLongIterator:
+    """LazyLongIterator.java:28-44 over a decoded successor array (LazyLongIterators.wrap, :220-255)."""
+
+    def __init__(self, arr):
+        self._a = arr
+        self._i = 0
+
+    def next_long(self):
+        if self._i >= len(self._a):
+            return -1
+        v = int(self._a[self._i]); self._i += 1
+        return v
+
+    nextLong = next_long
+
+    def skip(self, n):
+        k = min(int(n), len(self._a) - self._i)
+        self._i += k
+        return k
+
+    def __iter__(self):
+        while True:
+            v = self.next_long()
+            if v == -1:
+                return
+            yield v
+
+
+class NodeIterator:
+    """BVGraph.BVGraphNodeIterator (BVGraph.java:1100-1245) fed by batched GPU decodes."""
+
+    def __init__(self, graph, frm, upper_bound=None, batch_nodes=None):
+        n = graph.num_nodes()
+        if frm < 0 or frm > n:
+            raise IllegalArgumentException(_abi.E_ARG, "nodeIterator(%d)" % frm)        # BVG:1128
+        self._g = graph
+        self._from = frm
+        self._curr = frm - 1                                                           # BVG:1147
+        self._limit = min(upper_bound if upper_bound is not None else n, n) - 1         # BVG:1148
+        self._batch_nodes = batch_nodes or graph.iterator_batch_nodes
+        self._b0 = frm; self._b1 = frm
+        self._deg = None; self._cum = None; self._succ = None
+
+    def has_next(self):
+        return self._curr < self._limit                                                # BVG:1179-1181
+
+    hasNext = has_next
+
+    def _fill(self, x):
+        hi = min(x + self._batch_nodes, self._limit + 1)
+        deg, succ = self._g.decode_range(x, hi)
+        self._b0, self._b1 = x, hi
+        self._deg = deg
+        self._cum = np.zeros(len(deg) + 1, dtype=np.int64)
+        np.cumsum(deg, out=self._cum[1:])
+        self._succ = succ
+
+    def next_long(self):
+        if not self.has_next():
+            raise NoSuchElementException()                                             # BVG:1165
+        self._curr += 1
+        if not (self._b0 <= self._curr < self._b1):
+            self._fill(self._curr)
+        return self._curr
+
+    nextLong = next_long
+
+    def __iter__(self):
+        while self.has_next():
+            yield self.next_long()
+
+    def _require_started(self):
+        if self._curr == self._from - 1:
+            raise IllegalStateException(_abi.E_STATE, "no node fetched yet")            # BVG:1185,1193,1207
+
+    def outdegree(self):
+        self._require_started()
+        return int(self._deg[self._curr - self._b0])
+
+    def successor_array(self):
+        """successorBigArray(): view valid until the next next_long() (NodeIterator.java:80-96)."""
+        self._require_started()
+        i = self._curr - self._b0
+        return self._succ[self._cum[i]:self._cum[i + 1]]
+
+    successorBigArray = successor_array
+
+    def successors(self):
+        return LazyLongIterator(self.successor_array())
+
+    def copy(self, upper_bound=None):
+        """NodeIterator.copy(upperBound), BVG:1223-1229: a new iterator positioned after the current node."""
+        ub = self._limit + 1 if upper_bound is None else upper_bound
+        return NodeIterator(self._g.copy(), self._curr + 1, ub, self._batch_nodes)
+
+    def skip(self, n):
+        k = 0
+        while k < n and self.has_next():
+            self.next_long(); k += 1
+        return k
+
+
+class BVGraph:
+    """ImmutableGraph / BVGraph surface for the decode path, backed by HBM-resident data."""
+
+    iterator_batch_nodes = 1 << 16
+
+    def __init__(self, handle, keep=()):
+        self._h = handle
+        self._keep = keep
+        self._params = Params()
+        _check(lib().bvg_info(self._h, C.byref(self._params)), "info")
+        self._basename = None
+
+    # ---- loading (BVGraph.java:1345-1464) ----
+    @classmethod
+    def load(cls, basename, device=0, mode=_abi.LOAD_STANDARD):
+        h = C.c_void_p()
+        _check(lib().bvg_open(os.fsencode(basename), mode, device, C.byref(h)), "load(%s)" % basename)
+        g = cls(h); g._basename = basename
+        return g
+
+    @classmethod
+    def load_mapped(cls, basename, device=0):
+        return cls.load(basename, device, _abi.LOAD_MAPPED)
+
+    @classmethod
+    def load_offline(cls, basename, device=0):
+        return cls.load(basename, device, _abi.LOAD_OFFLINE)
+
+    @classmethod
+    def load_sequential(cls, basename, device=0):
+        return cls.load(basename, device, _abi.LOAD_SEQUENTIAL)
+
+    @classmethod
+    def from_memory(cls, params, graph_bytes, offsets, device=0):
+        g = np.frombuffer(bytes(graph_bytes), dtype=np.uint8) if not isinstance(graph_bytes, np.ndarray) else np.ascontiguousarray(graph_bytes, dtype=np.uint8)
+        o = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().bvg_open_mem(C.byref(params), g.ctypes.data if len(g) else None, len(g), None if o is None else o.ctypes.data, device, C.byref(h)), "open_mem")
+        return cls(h)
+
+    @classmethod
+    def from_device(cls, params, d_graph_ptr, nbytes, d_offsets_ptr, device=0, keep=()):
+        """Adopts buffers already resident in HBM (e.g. torch tensors; pass them in `keep`)."""
+        h = C.c_void_p()
+        _check(lib().bvg_open_dev(C.byref(params), d_graph_ptr, nbytes, d_offsets_ptr, device, C.byref(h)), "open_dev")
+        return cls(h, keep=keep)
+
+    def tile(self, copies):
+        """Synthetic workload helper: `copies` back-to-back copies of this graph (bvg_tile)."""
+        h = C.c_void_p()
+        _check(lib().bvg_tile(self._h, copies, C.byref(h)), "tile")
+        return BVGraph(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bvg_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- ImmutableGraph surface ----
+    @property
+    def params(self):
+        return self._params
+
+    def num_nodes(self):
+        return int(self._params.nodes)
+
+    def num_arcs(self):
+        if self._params.arcs < 0:
+            raise UnsupportedOperationException(_abi.E_UNSUPPORTED, "numArcs")           # ImmutableGraph.java:253-258
+        return int(self._params.arcs)
+
+    numNodes, numArcs = num_nodes, num_arcs
+
+    def random_access(self):
+        return True
+
+    def has_copiable_iterators(self):
+        return True
+
+    def basename(self):
+        return self._basename
+
+    def window_size(self):
+        return int(self._params.window_size)
+
+    def max_ref_count(self):
+        return int(self._params.max_ref_count)
+
+    def min_interval_length(self):
+        return int(self._params.min_interval_length)
+
+    def copy(self):
+        """BVGraph.copy() (BVGraph.java:553-578): shares the device data, own stream/workspace."""
+        h = C.c_void_p()
+        _check(lib().bvg_copy(self._h, C.byref(h)), "copy")
+        g = BVGraph(h); g._basename = self._basename
+        return g
+
+    def set_node_base(self, base):
+        _check(lib().bvg_set_node_base(self._h, base), "set_node_base")
+
+    def set_tuning(self, block_bits=0, force_wide=False, force_slow=False):
+        t = Tuning(block_bits, int(force_wide), int(force_slow), 0)
+        _check(lib().bvg_set_tuning(self._h, C.byref(t)), "set_tuning")
+
+    def offsets(self):
+        out = np.empty(self.num_nodes() + 1, dtype=np.uint64)
+        _check(lib().bvg_get_offsets(self._h, out.ctypes.data), "get_offsets")
+        return out
+
+    def outdegrees(self, frm=0, to=None):
+        to = self.num_nodes() if to is None else to
+        out = np.empty(max(to - frm, 0), dtype=np.int32)
+        _check(lib().bvg_outdegrees(self._h, frm, to, out.ctypes.data if len(out) else None) if to > frm else (0 if 0 <= frm <= self.num_nodes() else _abi.E_ARG), "outdegrees")
+        return out
+
+    def outdegree(self, x):
+        if x < 0 or x >= self.num_nodes():
+            raise IllegalArgumentException(_abi.E_ARG, "outdegree(%d)" % x)               # BVG:823
+        return int(self.outdegrees(x, x + 1)[0])
+
+    def decode_range(self, frm, to):
+        """(outdeg int32[to-frm], succ int64[sum]) of nodes [frm,to) — bit-exact with nodeIterator(frm)."""
+        if frm < 0 or to > self.num_nodes() or frm > to:
+            raise IllegalArgumentException(_abi.E_ARG, "decode_range(%d,%d)" % (frm, to))
+        cnt = to - frm
+        deg = np.empty(max(cnt, 1), dtype=np.int32)
+        need = C.c_uint64(0)
+        cap = max(1024, 16 * cnt)
+        while True:
+            succ = np.empty(cap, dtype=np.int64)
+            st = lib().bvg_decode_range(self._h, frm, to, deg.ctypes.data, succ.ctypes.data, cap, C.byref(need))
+            if st == _abi.E_CAPACITY:
+                cap = int(need.value)
+                continue
+            _check(st, "decode_range(%d,%d)" % (frm, to))
+            return deg[:cnt], succ[:need.value]
+
+    def successor_array(self, x):
+        if x < 0 or x >= self.num_nodes():
+            raise IllegalArgumentException(_abi.E_ARG, "successors(%d)" % x)              # BVG:863
+        return self.decode_range(x, x + 1)[1]
+
+    successorBigArray = successor_array
+
+    def successors(self, x):
+        return LazyLongIterator(self.successor_array(x))
+
+    def node_iterator(self, frm=0):
+        return NodeIterator(self, frm)
+
+    nodeIterator = node_iterator
+
+    def split_node_iterators(self, how_many):
+        """ImmutableGraph.splitNodeIterators (ImmutableGraph.java:405-436): ceil(n/k)-sized ranges."""
+        n = self.num_nodes()
+        if how_many <= 0:
+            raise IllegalArgumentException(_abi.E_ARG, "splitNodeIterators")
+        m = -(-n // how_many) if n else 0
+        its = []
+        for i in range(how_many):
+            lo = min(i * m, n)
+            hi = min(lo + m, n)
+            its.append(NodeIterator(self.copy(), lo, hi) if lo < n else NodeIterator(self, n, n))
+        return its
+
+    splitNodeIterators = split_node_iterators
+
+    def split_by_bits(self, k):
+        b = np.empty(k + 1, dtype=np.int64)
+        _check(lib().bvg_split_by_bits(self._h, k, b.ctypes.data), "split_by_bits")
+        return b
+
+    def scan(self, frm=0, to=None):
+        """Full sequential successor scan consumed on chip (SpeedTest.java:127-141): dict of bvg_scan_result."""
+        to = self.num_nodes() if to is None else to
+        r = ScanResult()
+        _check(lib().bvg_scan(self._h, frm, to, C.byref(r)), "scan(%d,%d)" % (frm, to))
+        return r.as_dict()

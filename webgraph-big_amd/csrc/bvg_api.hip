@@ -1,0 +1,650 @@
+// bvg_api.hip — host side of libbvgraph_hip.so: the C ABI of include/bvgraph_hip.h.
+//
+// Mirrors the load path of the reference (ImmutableGraph.load -> BVGraph.loadInternal,
+// BVGraph.java:1479-1574): parse .properties, bring .graph into memory (here: HBM), decode the
+// .offsets gaps into an index (here: a device array instead of an Elias-Fano list), then serve
+// outdegree / successors / sequential scans — all of which run as HIP kernels (bvg_kernels.hip).
+// There is no CPU decode path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bvg_kernels.h"
+
+using namespace bvg;
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP;                         \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+constexpr uint32_t kDefaultBlockBits = 32768;   // ~4 KiB of compressed stream per wavefront
+constexpr uint64_t kPad = 64;                   // zero bytes after the stream (8-byte loads + record overruns)
+
+struct Plan {
+    uint32_t block_bits = 0;
+    uint32_t nblk = 0;
+    uint64_t* d_first = nullptr; uint32_t* d_halo = nullptr; uint64_t* d_mask = nullptr;
+    std::vector<uint64_t> h_first;
+    void release() {
+        if (d_first) (void)hipFree(d_first);
+        if (d_halo) (void)hipFree(d_halo);
+        if (d_mask) (void)hipFree(d_mask);
+        d_first = nullptr; d_halo = nullptr; d_mask = nullptr; nblk = 0; h_first.clear();
+    }
+};
+
+struct Shared {
+    int device = 0;
+    bvg_params p{};
+    uint8_t* d_graph = nullptr; uint64_t nbytes = 0; bool own_graph = false;
+    uint64_t* d_offsets = nullptr; bool own_offsets = false;
+    uint64_t total_bits = 0;
+    bool wide = false;
+    Plan plan; std::mutex mu;
+    std::atomic<int> refs{1};
+};
+
+}  // namespace
+
+struct bvg_graph {
+    Shared* sh = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* d_acc = nullptr;      // 4 words
+    uint32_t* d_fail = nullptr;               // [0] count, [1..] list
+    uint32_t fail_cap = 0;
+    uint64_t node_base = 0;
+    bvg_tuning tun{};
+};
+
+namespace {
+
+Codings codings_of(const bvg_params& p) {
+    Codings c; c.outdegree = p.outdegree_coding; c.block = p.block_coding; c.residual = p.residual_coding;
+    c.reference = p.reference_coding; c.block_count = p.block_count_coding; c.zeta_k = p.zeta_k;
+    return c;
+}
+
+int check_params(const bvg_params& p) {
+    auto in = [](int v, std::initializer_list<int> s) { for (int x : s) if (x == v) return true; return false; };
+    if (p.nodes < 0) return BVG_E_ARG;
+    if (!in(p.outdegree_coding, {BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;                       // BVG:655-659
+    if (!in(p.reference_coding, {BVG_UNARY, BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;            // BVG:695-700
+    if (!in(p.block_count_coding, {BVG_UNARY, BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;          // BVG:729-734
+    if (!in(p.block_coding, {BVG_UNARY, BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;                // BVG:759-764
+    if (!in(p.residual_coding, {BVG_GAMMA, BVG_ZETA, BVG_DELTA, BVG_GOLOMB, BVG_NIBBLE})) return BVG_E_UNSUPPORTED;  // BVG:788-795
+    if (!in(p.offset_coding, {BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;                          // BVG:628-632
+    if (p.window_size < 0 || p.window_size > kMaxWindow) return BVG_E_UNSUPPORTED;
+    if (p.min_interval_length < 0) return BVG_E_ARG;
+    if (p.residual_coding == BVG_ZETA && (p.zeta_k < 1 || p.zeta_k > 32)) return BVG_E_ARG;
+    return 0;
+}
+
+// Host-side MSB-first reader for the .offsets file only (one-off at load).
+struct HostBits {
+    const uint8_t* p; uint64_t nbits, pos = 0; bool eof = false;
+    uint64_t peek() const {
+        uint64_t byte = pos >> 3, nb = nbits >> 3; uint64_t hi = 0; uint8_t nx = 0;
+        for (int i = 0; i < 8; i++) hi = (hi << 8) | (byte + i < nb ? p[byte + i] : 0);
+        nx = byte + 8 < nb ? p[byte + 8] : 0;
+        unsigned sh = (unsigned)(pos & 7);
+        return sh ? (hi << sh) | ((uint64_t)nx >> (8 - sh)) : hi;
+    }
+    uint64_t bits(unsigned n) { if (!n) return 0; uint64_t w = peek(); pos += n; if (pos > nbits) eof = true; return w >> (64 - n); }
+    uint64_t unary() {
+        uint64_t z = 0;
+        for (;;) {
+            uint64_t w = peek();
+            if (w) { unsigned lz = (unsigned)__builtin_clzll(w); pos += lz + 1; if (pos > nbits) eof = true; return z + lz; }
+            pos += 64; z += 64;
+            if (pos >= nbits) { eof = true; return z; }
+        }
+    }
+    uint64_t gamma() { uint64_t m = unary(); if (m > 63) { eof = true; return 0; } return ((1ull << m) | bits((unsigned)m)) - 1; }
+    uint64_t delta() { uint64_t m = gamma(); if (m > 63) { eof = true; return 0; } return ((1ull << m) | bits((unsigned)m)) - 1; }
+};
+
+int read_file(const std::string& path, std::vector<uint8_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return BVG_E_IO;
+    fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+    out.resize((size_t)sz);
+    if (sz && fread(out.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return BVG_E_IO; }
+    fclose(f);
+    return 0;
+}
+
+int make_handle(Shared* sh, bvg_graph** out) {
+    bvg_graph* g = new bvg_graph();
+    g->sh = sh;
+    HIPCHK(hipSetDevice(sh->device));
+    HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&g->ev0));
+    HIPCHK(hipEventCreate(&g->ev1));
+    HIPCHK(hipMalloc(&g->d_acc, 4 * sizeof(unsigned long long)));
+    g->fail_cap = 1u << 16;
+    HIPCHK(hipMalloc(&g->d_fail, (g->fail_cap + 1) * sizeof(uint32_t)));
+    *out = g;
+    return 0;
+}
+
+void release_shared(Shared* sh) {
+    if (sh->refs.fetch_sub(1) != 1) return;
+    (void)hipSetDevice(sh->device);
+    sh->plan.release();
+    if (sh->own_graph && sh->d_graph) (void)hipFree(sh->d_graph);
+    if (sh->own_offsets && sh->d_offsets) (void)hipFree(sh->d_offsets);
+    delete sh;
+}
+
+int ensure_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return BVG_E_HIP;
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+
+// Builds the block plan: boundaries at ~equal compressed bits + per-block halo masks.
+int build_plan(bvg_graph* g, uint32_t block_bits) {
+    Shared* sh = g->sh;
+    std::lock_guard<std::mutex> lk(sh->mu);
+    if (sh->plan.nblk && sh->plan.block_bits == block_bits) return 0;
+    sh->plan.release();
+    sh->plan.block_bits = block_bits;
+    const int64_t n = sh->p.nodes;
+    if (n == 0) { sh->plan.nblk = 0; sh->plan.h_first.assign(1, 0); return 0; }
+    const uint64_t limit = sh->nbytes;
+    uint64_t nb = (sh->total_bits + block_bits - 1) / block_bits;
+    if (nb == 0) nb = 1;
+    if (nb > 0x7FFFFFF0ull) return BVG_E_UNSUPPORTED;
+    uint64_t* d_first0 = nullptr;
+    HIPCHK(hipMalloc(&d_first0, (nb + 1) * sizeof(uint64_t)));
+    launch_plan_boundaries(sh->d_offsets, n, block_bits, nb, d_first0, g->stream);
+    std::vector<uint64_t> first(nb + 1);
+    HIPCHK(hipMemcpyAsync(first.data(), d_first0, (nb + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    (void)hipFree(d_first0);
+    // drop empty blocks (a record longer than block_bits spans several targets)
+    first[0] = 0;
+    std::vector<uint64_t> uniq; uniq.reserve(first.size());
+    for (size_t i = 0; i < first.size(); i++) if (uniq.empty() || first[i] != uniq.back()) uniq.push_back(first[i]);
+    if (uniq.back() != (uint64_t)n) uniq.push_back((uint64_t)n);
+    uint32_t nblk = (uint32_t)(uniq.size() - 1);
+    // halo per boundary; boundaries whose reference chains reach further back than kMaxHalo nodes are removed
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t* d_first = nullptr; uint32_t* d_halo = nullptr; uint64_t* d_mask = nullptr;
+        HIPCHK(hipMalloc(&d_first, (nblk + 1) * sizeof(uint64_t)));
+        HIPCHK(hipMalloc(&d_halo, (size_t)nblk * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&d_mask, (size_t)nblk * sizeof(uint64_t)));
+        HIPCHK(hipMemcpyAsync(d_first, uniq.data(), (nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
+        launch_plan_halo(sh->d_graph, limit, sh->d_offsets, n, d_first, nblk, sh->p.window_size, codings_of(sh->p), d_halo, d_mask, g->stream);
+        std::vector<uint32_t> halo(nblk);
+        HIPCHK(hipMemcpyAsync(halo.data(), d_halo, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        bool any_bad = false;
+        for (uint32_t k = 0; k < nblk; k++) if (halo[k] == 0xFFFFFFFFu) { any_bad = true; break; }
+        if (!any_bad || pass == 1) {
+            if (any_bad) { (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask); return BVG_E_UNSUPPORTED; }
+            sh->plan.d_first = d_first; sh->plan.d_halo = d_halo; sh->plan.d_mask = d_mask;
+            sh->plan.nblk = nblk; sh->plan.h_first = uniq;
+            return 0;
+        }
+        // merge blocks: drop un-cuttable boundaries (the halo of a kept boundary does not depend on the others)
+        std::vector<uint64_t> kept; kept.reserve(uniq.size());
+        for (uint32_t k = 0; k < nblk; k++) if (halo[k] != 0xFFFFFFFFu || k == 0) kept.push_back(uniq[k]);
+        kept.push_back((uint64_t)n);
+        uniq.swap(kept); nblk = (uint32_t)(uniq.size() - 1);
+        (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask);
+    }
+    return BVG_E_UNSUPPORTED;
+}
+
+uint32_t block_bits_of(const bvg_graph* g) { return g->tun.block_bits ? g->tun.block_bits : kDefaultBlockBits; }
+
+// Runs the decode kernel over the blocks intersecting [from,to); slow-path relaunches included.
+int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
+               bvg_scan_result* res) {
+    Shared* sh = g->sh;
+    int r = build_plan(g, block_bits_of(g)); if (r) return r;
+    const Plan& pl = sh->plan;
+    const bool wide = sh->wide || g->tun.force_wide;
+    // block range
+    const std::vector<uint64_t>& hf = pl.h_first;
+    uint32_t lo = (uint32_t)(std::upper_bound(hf.begin(), hf.end(), (uint64_t)from) - hf.begin());
+    lo = lo ? lo - 1 : 0;
+    uint32_t hi = (uint32_t)(std::lower_bound(hf.begin(), hf.end(), (uint64_t)to) - hf.begin());
+    if (hi > pl.nblk) hi = pl.nblk;
+    uint32_t nblocks = hi > lo ? hi - lo : 0;
+
+    HIPCHK(hipMemsetAsync(g->d_acc, 0, 4 * sizeof(unsigned long long), g->stream));
+    HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
+
+    DecodeArgs a{};
+    a.graph = sh->d_graph; a.limit_byte = sh->nbytes; a.offsets = sh->d_offsets; a.n = sh->p.nodes;
+    a.from = from; a.to = to;
+    a.blk_first = pl.d_first; a.blk_halo = pl.d_halo; a.blk_mask = pl.d_mask; a.work_list = nullptr; a.blk_lo = lo;
+    a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
+    a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
+    a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap;
+
+    uint32_t launches = 0, slow_blocks = 0;
+    std::vector<uint32_t> work;
+    HIPCHK(hipEventRecord(g->ev0, g->stream));
+    if (nblocks && !g->tun.force_slow) {
+        launch_decode(a, nblocks, wide, materialise, false, g->stream);
+        launches++;
+    }
+    HIPCHK(hipEventRecord(g->ev1, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    double kernel_ms = ms;
+
+    if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = lo + i; }
+    else {
+        uint32_t nfail = 0;
+        HIPCHK(hipMemcpy(&nfail, g->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (nfail > g->fail_cap) return BVG_E_NOMEM;     // pathological: > 64K oversized blocks
+        work.resize(nfail);
+        if (nfail) HIPCHK(hipMemcpy(work.data(), g->d_fail + 1, nfail * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    slow_blocks = (uint32_t)work.size();
+
+    // slow path: same kernel over global-memory pools; grow the pool until every block fits
+    uint64_t pool_elems = 1ull << 20;
+    const size_t esz = wide ? 8 : 4;
+    while (!work.empty()) {
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        uint64_t scr_elems = pool_elems / 2;
+        uint64_t per_wg = (pool_elems + scr_elems) * esz;
+        uint64_t max_wgs = (free_b / 2) / per_wg;
+        if (max_wgs == 0) return BVG_E_NOMEM;
+        uint32_t batch = (uint32_t)std::min<uint64_t>({(uint64_t)work.size(), max_wgs, 1024});
+        void *gpool = nullptr, *gscr = nullptr; uint32_t* d_work = nullptr;
+        HIPCHK(hipMalloc(&gpool, (size_t)batch * pool_elems * esz));
+        HIPCHK(hipMalloc(&gscr, (size_t)batch * scr_elems * esz));
+        HIPCHK(hipMalloc(&d_work, work.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(d_work, work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
+        a.gpool = gpool; a.gpool_elems = pool_elems; a.gscr = gscr; a.gscr_elems = scr_elems;
+        HIPCHK(hipEventRecord(g->ev0, g->stream));
+        for (size_t off = 0; off < work.size(); off += batch) {
+            uint32_t nb = (uint32_t)std::min<size_t>(batch, work.size() - off);
+            a.work_list = d_work + off;
+            launch_decode(a, nb, wide, materialise, true, g->stream);
+            launches++;
+        }
+        HIPCHK(hipEventRecord(g->ev1, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+        kernel_ms += ms;
+        uint32_t nfail = 0;
+        HIPCHK(hipMemcpy(&nfail, g->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        std::vector<uint32_t> next(nfail);
+        if (nfail) HIPCHK(hipMemcpy(next.data(), g->d_fail + 1, nfail * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        (void)hipFree(gpool); (void)hipFree(gscr); (void)hipFree(d_work);
+        work.swap(next);
+        if (!work.empty()) {
+            if (pool_elems >= (1ull << 34)) return BVG_E_NOMEM;
+            pool_elems *= 8;
+        }
+    }
+
+    unsigned long long acc[4];
+    HIPCHK(hipMemcpy(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost));
+    if (res) {
+        res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
+        res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;
+        res->index_bytes = (uint64_t)(to - from + 1) * 8 + (uint64_t)nblocks * 20;
+        res->graph_bytes = 0;
+    }
+    if (acc[3] & ERR_REF_RANGE) return BVG_E_STATE;
+    if (acc[3] & (ERR_OVERRUN | ERR_MALFORMED)) return BVG_E_EOF;
+    return 0;
+}
+
+int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph_in, uint64_t nbytes, const uint64_t* h_offsets,
+                const void* d_offsets_in, int device, bvg_graph** out) {
+    if (!p || !out) return BVG_E_ARG;
+    int r = check_params(*p); if (r) return r;
+    r = ensure_device(device); if (r) return r;
+    if (!h_offsets && !d_offsets_in) return BVG_E_STATE;    // sequential-only graphs: offsets derivation is a later row
+    Shared* sh = new Shared();
+    sh->device = device; sh->p = *p; sh->nbytes = nbytes;
+    sh->wide = p->nodes > (int64_t)0x7FFFFFFF;
+    const int64_t n = p->nodes;
+    if (d_graph_in) { sh->d_graph = (uint8_t*)d_graph_in; sh->own_graph = false; }
+    else {
+        uint64_t padded = ((nbytes + 15) & ~15ull) + kPad;
+        HIPCHK(hipMalloc(&sh->d_graph, padded));
+        sh->own_graph = true;
+        HIPCHK(hipMemset(sh->d_graph, 0, padded));
+        if (nbytes) HIPCHK(hipMemcpy(sh->d_graph, h_graph, nbytes, hipMemcpyHostToDevice));
+    }
+    if (d_offsets_in) { sh->d_offsets = (uint64_t*)d_offsets_in; sh->own_offsets = false; }
+    else {
+        HIPCHK(hipMalloc(&sh->d_offsets, ((size_t)n + 1) * sizeof(uint64_t)));
+        sh->own_offsets = true;
+        HIPCHK(hipMemcpy(sh->d_offsets, h_offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(&sh->total_bits, sh->d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (sh->total_bits > nbytes * 8) { release_shared(sh); return BVG_E_EOF; }
+    r = make_handle(sh, out);
+    if (r) { release_shared(sh); return r; }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int bvg_abi_version(void) { return BVG_ABI_VERSION; }
+
+void bvg_default_params(bvg_params* p) {
+    memset(p, 0, sizeof *p);
+    p->arcs = -1;
+    p->window_size = 7; p->max_ref_count = 3; p->min_interval_length = 4; p->zeta_k = 3;
+    p->outdegree_coding = BVG_GAMMA; p->block_coding = BVG_GAMMA; p->residual_coding = BVG_ZETA;
+    p->reference_coding = BVG_UNARY; p->block_count_coding = BVG_GAMMA; p->offset_coding = BVG_GAMMA;
+}
+
+int bvg_parse_properties(const char* text, size_t len, bvg_params* out) {
+    if (!text || !out) return BVG_E_ARG;
+    bvg_params p; bvg_default_params(&p);
+    bool have_nodes = false, have_class = false; long version = 0;
+    std::string t(text, len);
+    size_t i = 0;
+    auto trim = [](std::string s) {
+        size_t a = 0, b = s.size();
+        while (a < b && isspace((unsigned char)s[a])) a++;
+        while (b > a && isspace((unsigned char)s[b - 1])) b--;
+        return s.substr(a, b - a);
+    };
+    while (i < t.size()) {
+        size_t e = t.find_first_of("\r\n", i); if (e == std::string::npos) e = t.size();
+        std::string line = trim(t.substr(i, e - i));
+        i = e + 1;
+        if (line.empty() || line[0] == '#' || line[0] == '!') continue;
+        size_t sep = line.find_first_of("=:");
+        std::string key = trim(sep == std::string::npos ? line : line.substr(0, sep));
+        std::string val = sep == std::string::npos ? "" : trim(line.substr(sep + 1));
+        if (key == "nodes") { p.nodes = strtoll(val.c_str(), nullptr, 10); have_nodes = true; }
+        else if (key == "arcs") p.arcs = strtoll(val.c_str(), nullptr, 10);
+        else if (key == "windowsize") p.window_size = (int32_t)strtol(val.c_str(), nullptr, 10);
+        else if (key == "maxrefcount") p.max_ref_count = (int32_t)strtol(val.c_str(), nullptr, 10);
+        else if (key == "minintervallength") p.min_interval_length = (int32_t)strtol(val.c_str(), nullptr, 10);
+        else if (key == "zetak") p.zeta_k = (int32_t)strtol(val.c_str(), nullptr, 10);
+        else if (key == "version") version = strtol(val.c_str(), nullptr, 10);
+        else if (key == "graphclass") {
+            if (val.rfind("class ", 0) == 0) val = val.substr(6);
+            if (val != "it.unimi.dsi.big.webgraph.BVGraph" && val != "it.unimi.dsi.webgraph.BVGraph") return BVG_E_IO;   // BVG:1491
+            have_class = true;
+        } else if (key == "compressionflags") {
+            size_t s = 0;
+            while (s <= val.size()) {
+                size_t b = val.find('|', s); if (b == std::string::npos) b = val.size();
+                std::string f = trim(val.substr(s, b - s));
+                s = b + 1;
+                if (f.empty()) continue;
+                static const struct { const char* prefix; int field; unsigned allowed; } F[] = {
+                    {"OUTDEGREES_", 0, 1u << BVG_GAMMA | 1u << BVG_DELTA},
+                    {"BLOCKS_", 1, 1u << BVG_GAMMA | 1u << BVG_DELTA},
+                    {"RESIDUALS_", 2, 1u << BVG_GAMMA | 1u << BVG_ZETA | 1u << BVG_DELTA | 1u << BVG_NIBBLE | 1u << BVG_GOLOMB},
+                    {"REFERENCES_", 3, 1u << BVG_GAMMA | 1u << BVG_DELTA | 1u << BVG_UNARY},
+                    {"BLOCK_COUNT_", 4, 1u << BVG_GAMMA | 1u << BVG_DELTA | 1u << BVG_UNARY},
+                    {"OFFSETS_", 5, 1u << BVG_GAMMA | 1u << BVG_DELTA}};
+                static const struct { const char* name; int id; } N[] = {{"DELTA", BVG_DELTA}, {"GAMMA", BVG_GAMMA}, {"GOLOMB", BVG_GOLOMB},
+                    {"SKEWED_GOLOMB", BVG_SKEWED_GOLOMB}, {"UNARY", BVG_UNARY}, {"ZETA", BVG_ZETA}, {"NIBBLE", BVG_NIBBLE}};
+                bool ok = false;
+                for (auto& fd : F) {
+                    size_t pl = strlen(fd.prefix);
+                    if (f.compare(0, pl, fd.prefix) != 0) continue;
+                    std::string nm = f.substr(pl);
+                    for (auto& nn : N) if (nm == nn.name && (fd.allowed >> nn.id & 1u)) {
+                        int32_t* dst[] = {&p.outdegree_coding, &p.block_coding, &p.residual_coding, &p.reference_coding, &p.block_count_coding, &p.offset_coding};
+                        *dst[fd.field] = nn.id; ok = true;
+                    }
+                    if (ok) break;
+                }
+                if (!ok) return BVG_E_IO;                                           // "Compression flag unknown", BVG:1326
+            }
+        }
+    }
+    if (!have_nodes || !have_class) return BVG_E_IO;
+    if (version > 0) return BVG_E_IO;                                               // BVG:1496-1497
+    *out = p;
+    return 0;
+}
+
+int bvg_decode_offsets(const uint8_t* obytes, size_t nbytes, int64_t nodes, int coding, uint64_t* out) {
+    if (!obytes || !out || nodes < 0) return BVG_E_ARG;
+    if (coding != BVG_GAMMA && coding != BVG_DELTA) return BVG_E_UNSUPPORTED;      // BVG:628-632
+    HostBits b{obytes, (uint64_t)nbytes * 8};
+    uint64_t off = 0;
+    for (int64_t i = 0; i <= nodes; i++) {                                          // n+1 gaps, BVG:885
+        off += coding == BVG_DELTA ? b.delta() : b.gamma();
+        if (b.eof) return BVG_E_EOF;
+        out[i] = off;
+    }
+    return 0;
+}
+
+int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out) {
+    if (!basename || !out) return BVG_E_ARG;
+    if (load_mode < BVG_LOAD_OFFLINE || load_mode > BVG_LOAD_MAPPED) return BVG_E_ARG;
+    std::string base(basename);
+    std::vector<uint8_t> props, graph, offs;
+    int r = read_file(base + ".properties", props); if (r) return r;
+    bvg_params p;
+    r = bvg_parse_properties((const char*)props.data(), props.size(), &p); if (r) return r;
+    r = read_file(base + ".graph", graph); if (r) return r;
+    // The index is needed by every GPU entry point; sequential/offline modes use it too when present.
+    r = read_file(base + ".offsets", offs);
+    if (r) return load_mode >= BVG_LOAD_STANDARD ? BVG_E_IO : BVG_E_STATE;
+    std::vector<uint64_t> offsets((size_t)p.nodes + 1);
+    r = bvg_decode_offsets(offs.data(), offs.size(), p.nodes, p.offset_coding, offsets.data()); if (r) return r;
+    return open_common(&p, graph.data(), nullptr, graph.size(), offsets.data(), nullptr, device, out);
+}
+
+int bvg_open_mem(const bvg_params* p, const uint8_t* graph, uint64_t nbytes, const uint64_t* offsets, int device, bvg_graph** out) {
+    if (!graph && nbytes) return BVG_E_ARG;
+    return open_common(p, graph, nullptr, nbytes, offsets, nullptr, device, out);
+}
+
+int bvg_open_dev(const bvg_params* p, const void* d_graph, uint64_t nbytes, const void* d_offsets, int device, bvg_graph** out) {
+    if (!d_graph || !d_offsets) return BVG_E_ARG;
+    return open_common(p, nullptr, d_graph, nbytes, nullptr, d_offsets, device, out);
+}
+
+int bvg_copy(const bvg_graph* g, bvg_graph** out) {
+    if (!g || !out) return BVG_E_ARG;
+    g->sh->refs.fetch_add(1);
+    int r = make_handle(g->sh, out);
+    if (r) { release_shared(g->sh); return r; }
+    (*out)->node_base = g->node_base; (*out)->tun = g->tun;
+    return 0;
+}
+
+void bvg_close(bvg_graph* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->sh->device);
+    if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->d_acc) (void)hipFree(g->d_acc);
+    if (g->d_fail) (void)hipFree(g->d_fail);
+    release_shared(g->sh);
+    delete g;
+}
+
+int bvg_info(const bvg_graph* g, bvg_params* out) { if (!g || !out) return BVG_E_ARG; *out = g->sh->p; return 0; }
+int bvg_set_node_base(bvg_graph* g, uint64_t node_base) { if (!g) return BVG_E_ARG; g->node_base = node_base; return 0; }
+int bvg_set_tuning(bvg_graph* g, const bvg_tuning* t) { if (!g || !t) return BVG_E_ARG; g->tun = *t; return 0; }
+
+int bvg_get_offsets(bvg_graph* g, uint64_t* out) {
+    if (!g || !out) return BVG_E_ARG;
+    HIPCHK(hipSetDevice(g->sh->device));
+    HIPCHK(hipMemcpy(out, g->sh->d_offsets, ((size_t)g->sh->p.nodes + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out) {
+    if (!g || !out) return BVG_E_ARG;
+    if (from < 0 || to > g->sh->p.nodes || from > to) return BVG_E_ARG;            // BVG:823
+    if (from == to) return 0;
+    HIPCHK(hipSetDevice(g->sh->device));
+    int32_t* d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)(to - from) * sizeof(int32_t)));
+    launch_outdegrees(g->sh->d_graph, g->sh->nbytes, g->sh->d_offsets, from, to, g->sh->p.outdegree_coding, d, nullptr, g->stream);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)(to - from) * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)hipFree(d);
+    return e == hipSuccess ? 0 : BVG_E_HIP;
+}
+
+static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t cap, uint64_t* n_succ, bool dev) {
+    if (!g) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    if (from < 0 || to > sh->p.nodes || from > to) return BVG_E_ARG;               // BVG:863,1000,1128
+    if (from == to) { if (n_succ) *n_succ = 0; return 0; }
+    HIPCHK(hipSetDevice(sh->device));
+    const int64_t cnt = to - from;
+    int32_t* d_deg = nullptr; uint64_t* d_cum = nullptr; uint64_t* d_tmp = nullptr; int64_t* d_succ = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        if (d_deg && !(dev && outdeg)) (void)hipFree(d_deg);
+        if (d_cum) (void)hipFree(d_cum);
+        if (d_tmp) (void)hipFree(d_tmp);
+        if (d_succ && !dev) (void)hipFree(d_succ);
+    };
+#define DR_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP; } } while (0)
+    if (dev && outdeg) d_deg = outdeg; else DR_CHK(hipMalloc(&d_deg, (size_t)cnt * sizeof(int32_t)));
+    DR_CHK(hipMalloc(&d_cum, ((size_t)cnt + 1) * sizeof(uint64_t)));
+    DR_CHK(hipMalloc(&d_tmp, scan_tmp_elems(cnt) * sizeof(uint64_t)));
+    launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
+    launch_exclusive_scan(d_deg, d_cum, cnt, d_tmp, g->stream);
+    uint64_t total = 0;
+    DR_CHK(hipMemcpyAsync(&total, d_cum + cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    DR_CHK(hipStreamSynchronize(g->stream));
+    if (n_succ) *n_succ = total;
+    if (total > cap || (!succ && total > 0)) {          // query / too small: report the size (and the outdegrees)
+        if (outdeg && !dev) DR_CHK(hipMemcpy(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        cleanup();
+        return BVG_E_CAPACITY;
+    }
+    if (dev) d_succ = succ; else DR_CHK(hipMalloc(&d_succ, (size_t)(total ? total : 1) * sizeof(int64_t)));
+    rc = run_decode(g, from, to, true, d_cum, d_succ, d_deg, nullptr);
+    if (rc == 0 && !dev) {
+        if (total) DR_CHK(hipMemcpy(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (outdeg) DR_CHK(hipMemcpy(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    cleanup();
+#undef DR_CHK
+    return rc;
+}
+
+int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
+    return decode_range_impl(g, from, to, outdeg, succ, succ_cap, n_succ, false);
+}
+int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ) {
+    return decode_range_impl(g, from, to, (int32_t*)d_outdeg, (int64_t*)d_succ, succ_cap, n_succ, true);
+}
+
+int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) {
+    if (!g || !out) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    if (from < 0 || to > sh->p.nodes || from > to) return BVG_E_ARG;
+    memset(out, 0, sizeof *out);
+    if (from == to) return 0;
+    HIPCHK(hipSetDevice(sh->device));
+    int r = run_decode(g, from, to, false, nullptr, nullptr, nullptr, out);
+    // algorithmic bytes: the compressed bytes covering [from,to)
+    uint64_t b[2];
+    HIPCHK(hipMemcpy(&b[0], sh->d_offsets + from, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&b[1], sh->d_offsets + to, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    out->graph_bytes = (b[1] + 7) / 8 - b[0] / 8;
+    return r;
+}
+
+int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) {
+    if (!g || !bounds || k < 1) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    HIPCHK(hipSetDevice(sh->device));
+    const int64_t n = sh->p.nodes;
+    if (n == 0) { for (int i = 0; i <= k; i++) bounds[i] = 0; return 0; }
+    uint64_t per = (sh->total_bits + (uint64_t)k - 1) / (uint64_t)k; if (per == 0) per = 1;
+    uint64_t* d_first = nullptr;
+    HIPCHK(hipMalloc(&d_first, ((size_t)k + 1) * sizeof(uint64_t)));
+    launch_plan_boundaries(sh->d_offsets, n, per, (uint64_t)k, d_first, g->stream);
+    std::vector<uint64_t> f((size_t)k + 1);
+    hipError_t e = hipMemcpyAsync(f.data(), d_first, ((size_t)k + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)hipFree(d_first);
+    if (e != hipSuccess) return BVG_E_HIP;
+    for (int i = 0; i <= k; i++) bounds[i] = (int64_t)f[(size_t)i];
+    bounds[0] = 0; bounds[k] = n;
+    return 0;
+}
+
+int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) {
+    if (!base || !out || copies < 1) return BVG_E_ARG;
+    Shared* b = base->sh;
+    HIPCHK(hipSetDevice(b->device));
+    const int64_t n = b->p.nodes;
+    if (n <= 0 || b->total_bits == 0) return BVG_E_ARG;
+    if (copies > INT64_MAX / n) return BVG_E_ARG;
+    const uint64_t total_bits = b->total_bits * (uint64_t)copies;
+    const uint64_t nbytes = (total_bits + 7) / 8;
+    const uint64_t padded = ((nbytes + 15) & ~15ull) + kPad;
+    uint8_t* d_graph = nullptr; uint64_t* d_off = nullptr;
+    HIPCHK(hipMalloc(&d_graph, padded));
+    hipError_t e = hipMalloc(&d_off, ((size_t)(n * copies) + 1) * sizeof(uint64_t));
+    if (e != hipSuccess) { (void)hipFree(d_graph); return BVG_E_NOMEM; }
+    launch_tile_graph(b->d_graph, b->total_bits, d_graph, padded, copies, base->stream);
+    launch_tile_offsets(b->d_offsets, n, b->total_bits, d_off, copies, base->stream);
+    HIPCHK(hipStreamSynchronize(base->stream));
+    bvg_params p = b->p; p.nodes = n * copies; if (p.arcs >= 0) p.arcs *= copies;
+    int r = open_common(&p, nullptr, d_graph, nbytes, nullptr, d_off, b->device, out);
+    if (r) { (void)hipFree(d_graph); (void)hipFree(d_off); return r; }
+    (*out)->sh->own_graph = true; (*out)->sh->own_offsets = true;
+    (*out)->tun = base->tun;
+    return 0;
+}
+
+uint64_t bvg_arc_mix(uint64_t x, uint64_t y) {
+    uint64_t kx = splitmix64(x);
+    return mix_keyed((uint32_t)kx, (uint32_t)(kx >> 32) | 1u, y);
+}
+
+const char* bvg_strerror(int status) {
+    switch (status) {
+        case BVG_OK: return "ok";
+        case BVG_E_ARG: return "argument out of range (IllegalArgumentException)";
+        case BVG_E_STATE: return "illegal state: reference beyond window, or offsets unavailable (IllegalStateException)";
+        case BVG_E_UNSUPPORTED: return "unsupported coding / window / access mode (UnsupportedOperationException)";
+        case BVG_E_IO: return "cannot read or parse basename.{properties,graph,offsets} (IOException)";
+        case BVG_E_EOF: return "bit stream inconsistent with offsets or truncated (EOFException)";
+        case BVG_E_NOMEM: return "out of host or device memory";
+        case BVG_E_HIP: return "no gfx950 device or HIP runtime failure (this library has no CPU fallback)";
+        case BVG_E_CAPACITY: return "successor buffer too small";
+    }
+    return "unknown status";
+}
+
+}  // extern "C"

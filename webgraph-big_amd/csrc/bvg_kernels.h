@@ -1,0 +1,56 @@
+// bvg_kernels.h — launch interface between the host API (bvg_api.hip) and the kernels (bvg_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "bvg_device.h"
+
+namespace bvg {
+
+// LDS geometry of the fast (one wavefront per node block) decode kernel.
+constexpr int kRing = 256;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
+constexpr int kMaxWindow = 128;      // larger windows take the slow path only if a block needs it; beyond: unsupported
+constexpr int kMaxHalo = 64;         // halo nodes a block may need from before its first node (one row)
+
+struct DecodeArgs {
+    const uint8_t* graph; uint64_t limit_byte;
+    const uint64_t* offsets;            // n+1 bit positions
+    int64_t n;
+    int64_t from, to;                   // only nodes in [from,to) are reported
+    const uint64_t* blk_first;          // nblk+1 node ids
+    const uint32_t* blk_halo;           // halo length (<= kMaxHalo)
+    const uint64_t* blk_mask;           // bit j = node (first-1-j) is needed
+    const uint32_t* work_list;          // block ids to run, or nullptr = blockIdx.x + blk_lo
+    uint32_t blk_lo;
+    int window, min_interval;
+    Codings cod;
+    uint64_t node_base;
+    unsigned long long* acc;            // [0] arcs [1] chk [2] nodes [3] error bits
+    // materialise
+    const uint64_t* cum;                // exclusive prefix of outdegrees for nodes [from,to], or nullptr
+    int64_t* succ; int32_t* outdeg;
+    // slow path hand-off
+    uint32_t* fail_list; uint32_t* fail_count; uint32_t fail_cap;
+    // slow-path pools (global memory), per workgroup
+    void* gpool; uint64_t gpool_elems; void* gscr; uint64_t gscr_elems;
+};
+
+void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
+
+// thread per node: outdegree (BVG:821-842)
+void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,
+                       int outdegree_coding, int32_t* out, unsigned long long* total, hipStream_t s);
+// exclusive prefix sum of int32 -> uint64 (n+1 outputs), single stream, hand-written 3-phase scan
+void launch_exclusive_scan(const int32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s);
+size_t scan_tmp_elems(int64_t n);
+
+// plan: block boundaries at ~equal compressed bits, then per-boundary halo (reference-chain walk)
+void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s);
+void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first, uint32_t nblk,
+                      int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s);
+
+// synthetic tiling (bvg_tile)
+void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
+void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);
+
+}  // namespace bvg

@@ -1,0 +1,478 @@
+// bvg_kernels.hip — hand-written gfx950 kernels for BVGraph successor-list decoding.
+//
+// Replaces the reference's sequential hot loop (BVGraph.java:1164-1176 -> successors() :995-1097 ->
+// Masked/Merged/Interval iterators) with a block-parallel formulation:
+//
+//   * the node range is cut into BLOCKS of ~equal compressed size (plan_boundaries); one wavefront
+//     (a 64-thread workgroup) owns one block and walks it in ROWS of up to 64 consecutive nodes,
+//     one node per lane, each lane entering its record through the offsets index;
+//   * a row is decoded in two phases: (1) every lane parses its own record (outdegree, reference,
+//     copy blocks, intervals, residual gaps -> absolute residuals) into LDS; (2) a lock-step
+//     data-flow loop in which every lane emits ONE successor per iteration by a three-way merge of
+//     {masked copy of the referenced list, intervals, residuals}; a lane whose referenced list is
+//     being produced by a lower lane of the same row simply waits on that lane's `produced` counter,
+//     so reference chains pipeline instead of serialising;
+//   * the successor lists of the last `window` nodes stay in an LDS pool (compacted when full), so
+//     a block can be arbitrarily long with a bounded LDS footprint; only the first nodes of a block
+//     need a HALO: the (few) earlier nodes their reference chains reach, found by plan_halo;
+//   * in scan mode successors are consumed on chip (count + checksum, one atomic per block); in
+//     materialise mode each row's pool segment is copied out with coalesced 8-byte stores.
+//
+// Blocks that do not fit the LDS pool (a node whose list alone exceeds it) are handed to the same
+// kernel instantiated over a global-memory pool (the slow path).
+#include "bvg_kernels.h"
+
+namespace bvg {
+
+namespace {
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+
+template <typename T> struct PoolCfg;
+template <> struct PoolCfg<uint32_t> { static constexpr uint32_t pool = 3072, scr = 768; };
+template <> struct PoolCfg<uint64_t> { static constexpr uint32_t pool = 1536, scr = 384; };
+
+template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
+
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = __shfl_up(v, o, 64);
+        if ((int)lane_id() >= o) v += t;
+    }
+    return v;
+}
+
+template <typename T, bool MAT, bool SLOW>
+__global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
+    constexpr uint32_t RM = kRing - 1;
+    __shared__ T lds_pool[SLOW ? 1 : PoolCfg<T>::pool];
+    __shared__ T lds_scr[SLOW ? 1 : PoolCfg<T>::scr];
+    __shared__ uint64_t nd_base[kRing];
+    __shared__ uint32_t nd_d[kRing];
+    __shared__ uint32_t produced[64];
+    __shared__ uint32_t scr_used;
+
+    const unsigned lane = threadIdx.x;
+    const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
+    const int64_t s = (int64_t)a.blk_first[bid], e = (int64_t)a.blk_first[bid + 1];
+    if (e <= a.from || s >= a.to || s >= e) return;
+    const uint32_t halo = a.blk_halo[bid];
+    const uint64_t hmask = a.blk_mask[bid];
+    const int W = a.window;
+    const int64_t rep_lo = s > a.from ? s : a.from, rep_hi = e < a.to ? e : a.to;
+
+    T* const pool = SLOW ? reinterpret_cast<T*>(a.gpool) + (uint64_t)blockIdx.x * a.gpool_elems : lds_pool;
+    T* const scr = SLOW ? reinterpret_cast<T*>(a.gscr) + (uint64_t)blockIdx.x * a.gscr_elems : lds_scr;
+    const uint64_t CAP = SLOW ? a.gpool_elems : PoolCfg<T>::pool;
+    const uint64_t SCR = SLOW ? a.gscr_elems : PoolCfg<T>::scr;
+
+    for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
+    __syncthreads();
+
+    uint64_t pool_used = 0;
+    uint64_t blk_arcs = 0, blk_chk = 0, blk_nodes = 0;
+    unsigned err = 0;
+    bool failed = false;
+
+    int64_t r0 = s - (int64_t)halo;
+    while (r0 < e) {
+        // ------------------------------------------------------------------ row set-up
+        const int64_t x = r0 + lane;
+        const bool in_range = x < e;
+        const uint64_t hbit = x < s ? (uint64_t)(s - 1 - x) : 0;
+        const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
+        BitCursor cur{a.graph, 0, a.limit_byte};
+        uint64_t rec_end = 0;
+        uint32_t d = 0;
+        if (needed) {
+            cur.pos = a.offsets[x];
+            rec_end = a.offsets[x + 1];
+            d = (uint32_t)cur.read_coded(a.cod.outdegree, 0, rec_end);      // readOutdegree, BVG:654-660
+        }
+        // how many leading lanes fit in the pool?
+        uint64_t dclamp = d > CAP ? CAP + 1 : d;
+        uint64_t incl = wave_incl_scan64(dclamp);
+        uint64_t avail = CAP - pool_used;
+        uint64_t total = __shfl(incl, 63, 64);
+        if (total > avail && pool_used > 0) {
+            // compact: keep only the lists of the last W nodes, moved to the front of the pool
+            uint64_t my_d = 0, my_base = 0; int64_t y = r0 - W + (int64_t)lane;
+            const bool livelane = (int)lane < W && y >= s - (int64_t)halo && y >= 0;
+            if (livelane) { my_d = nd_d[(uint64_t)y & RM]; my_base = nd_base[(uint64_t)y & RM]; }
+            uint64_t nincl = wave_incl_scan64(my_d);
+            uint64_t nbase = nincl - my_d;
+            for (int j = 0; j < W && j < 64; j++) {
+                uint64_t src = __shfl(my_base, j, 64), dst = __shfl(nbase, j, 64), len = __shfl(my_d, j, 64);
+                if (src != dst)
+                    for (uint64_t t = lane; t < len; t += 64) { T v = pool[src + t]; pool[dst + t] = v; }
+            }
+            if (livelane) nd_base[(uint64_t)y & RM] = nbase;
+            pool_used = __shfl(nincl, 63, 64);
+            avail = CAP - pool_used;
+            __syncthreads();
+        }
+        unsigned k = 64;
+        if (total > avail) k = (unsigned)__popcll(ballot(incl <= avail));   // incl is monotone: a prefix of lanes
+        {
+            int64_t left_in_block = e - r0;
+            if ((int64_t)k > left_in_block) k = (unsigned)left_in_block;
+        }
+        if (k == 0) { failed = true; break; }                                // first node alone overflows the pool
+        const bool act = needed && lane < k;
+        const uint64_t base = pool_used + (incl - dclamp);
+        if (act) { nd_base[(uint64_t)x & RM] = base; nd_d[(uint64_t)x & RM] = d; }
+        pool_used += __shfl(incl, (int)k - 1, 64);
+        if (lane == 0) scr_used = 0;
+        produced[lane] = act ? 0u : kInf;
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase 1: parse own record
+        uint32_t ref = 0, bc = 0, ic = 0, nres = 0;
+        uint64_t sb = 0, ib = 0;
+        bool overflow = false;
+        if (act && d > 0) {
+            if (W > 0) {                                                     // BVG:1015
+                uint64_t r = cur.read_coded(a.cod.reference, 0, rec_end);   // readReference, BVG:692-703
+                if (r > (uint64_t)W || (int64_t)r > x) { err |= ERR_REF_RANGE; r = 0; }
+                ref = (uint32_t)r;
+            }
+            int64_t extra = d;
+            if (ref > 0) {                                                   // BVG:1020-1032
+                uint64_t nb = cur.read_coded(a.cod.block_count, 0, rec_end);
+                if (nb > rec_end - (cur.pos < rec_end ? cur.pos : rec_end) + 1) { err |= ERR_OVERRUN; nb = 0; }
+                bc = (uint32_t)nb;
+                sb = atomicAdd(&scr_used, bc);
+                if (sb + bc > SCR) { overflow = true; bc = 0; }
+                int64_t copied = 0, tot = 0;
+                for (uint32_t i = 0; i < bc; i++) {
+                    uint64_t b = cur.read_coded(a.cod.block, 0, rec_end) + (i ? 1 : 0);
+                    scr[sb + i] = (T)b;
+                    tot += (int64_t)b;
+                    if (!(i & 1)) copied += (int64_t)b;
+                    if (cur.pos > rec_end) { err |= ERR_OVERRUN; bc = i + 1; break; }
+                }
+                if (!(bc & 1)) copied += (int64_t)nd_d[(uint64_t)(x - ref) & RM] - tot;   // BVG:1030
+                extra = (int64_t)d - copied;
+                if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
+            }
+            if (extra > 0 && a.min_interval != 0) {                          // BVG:1037-1060 (always gamma)
+                uint64_t ni = cur.read_gamma(rec_end);
+                if (ni > (rec_end - (cur.pos < rec_end ? cur.pos : rec_end)) / 2 + 1) { err |= ERR_OVERRUN; ni = 0; }
+                ic = (uint32_t)ni;
+                ib = atomicAdd(&scr_used, 2 * ic);
+                if (ib + 2ull * ic > SCR) { overflow = true; ic = 0; }
+                int64_t prev = 0;
+                for (uint32_t i = 0; i < ic; i++) {
+                    int64_t left = i == 0 ? x + nat2int(cur.read_gamma(rec_end)) : prev + 1 + (int64_t)cur.read_gamma(rec_end);
+                    int64_t len = (int64_t)cur.read_gamma(rec_end) + a.min_interval;
+                    prev = left + len;
+                    extra -= len;
+                    scr[ib + 2 * i] = (T)left; scr[ib + 2 * i + 1] = (T)len;
+                    if (cur.pos > rec_end) { err |= ERR_OVERRUN; ic = i + 1; break; }
+                }
+                if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
+            }
+            nres = (uint32_t)extra;
+            if (nres > 0 && !overflow) {                                     // ResidualLongIterator, BVG:902-935
+                T* tail = pool + base + d - nres;
+                int64_t r = x + nat2int(cur.read_coded(a.cod.residual, a.cod.zeta_k, rec_end));
+                tail[0] = (T)r;
+                for (uint32_t t = 1; t < nres; t++) {
+                    r += (int64_t)cur.read_coded(a.cod.residual, a.cod.zeta_k, rec_end) + 1;
+                    tail[t] = (T)r;
+                    if (cur.pos > rec_end) { err |= ERR_OVERRUN; break; }
+                }
+            }
+            if (cur.pos != rec_end && !overflow) err |= ERR_MALFORMED;       // SURVEY A.6 self-check
+        }
+        if (ballot(overflow)) { failed = true; break; }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase 2: data-flow emission
+        const bool rep = act && x >= rep_lo && x < rep_hi;
+        uint32_t k0 = 0, k1 = 0;
+        if (rep && !MAT) { uint64_t kx = splitmix64((uint64_t)x + a.node_base); k0 = (uint32_t)kx; k1 = (uint32_t)(kx >> 32) | 1u; }
+        T* const out = pool + base;
+        const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; int rlane = -1;
+        if (act && ref > 0) {
+            const int64_t y = x - ref;
+            rl = pool + nd_base[(uint64_t)y & RM]; rlen = nd_d[(uint64_t)y & RM];
+            if (y >= r0) rlane = (int)lane - (int)ref;
+            if (bc == 0) keep = kInf;                                        // MaskedLongIterator.java:73-78
+            else {
+                keep = (uint32_t)scr[sb]; bi = 1;
+                if (keep == 0) {
+                    if (bi >= bc) rpos = rlen;
+                    else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
+                }
+            }
+        }
+        T ivcur = 0; uint32_t ivrem = 0, ivi = 0;
+        if (ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }
+        uint32_t rsi = 0;
+        T rhead = nres ? out[d - nres] : sentinel<T>();
+        uint32_t j = 0;
+        uint64_t chk = 0;
+        volatile uint32_t* vprod = produced;
+        for (;;) {
+            const bool todo = act && j < d;
+            if (!ballot(todo)) break;
+            const bool cneed = todo && rpos < rlen;
+            const bool cready = !cneed || rlane < 0 || vprod[rlane] > rpos;
+            if (todo && cready) {
+                const T c = cneed ? rl[rpos] : sentinel<T>();
+                const T iv = ivrem ? ivcur : sentinel<T>();
+                T m = c < iv ? c : iv; m = m < rhead ? m : rhead;            // MergedLongIterator.java:63-92, three-way
+                out[j] = m;
+                j++;
+                if (!MAT && rep) {
+                    const uint64_t y64 = m == sentinel<T>() ? ~0ull : (uint64_t)m + a.node_base;
+                    chk += mix_keyed(k0, k1, y64);
+                }
+                if (cneed && c == m) {                                       // MaskedLongIterator.java:81-100
+                    rpos++;
+                    if (--keep == 0) {
+                        if (bi >= bc) rpos = rlen;
+                        else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
+                    }
+                }
+                if (ivrem && iv == m) {                                      // LongIntervalSequenceIterator.java:71-78
+                    ivcur++;
+                    if (--ivrem == 0 && ivi < ic) { ivcur = scr[ib + 2 * ivi]; ivrem = (uint32_t)scr[ib + 2 * ivi + 1]; ivi++; }
+                }
+                if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? out[d - nres + rsi] : sentinel<T>(); }
+                vprod[lane] = j;
+            }
+        }
+        if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }
+
+        // ------------------------------------------------------------------ materialise: coalesced copy-out
+        if (MAT) {
+            __syncthreads();
+            const uint64_t repmask = ballot(rep);
+            if (repmask) {
+                const int la = __ffsll((unsigned long long)repmask) - 1;
+                const int lb = 63 - __clzll(repmask);
+                const uint64_t seg0 = __shfl(base, la, 64);
+                const uint64_t seg1 = __shfl(base + d, lb, 64);
+                const uint64_t dst0 = a.cum[(r0 + la) - a.from];
+                for (uint64_t t = lane; t < seg1 - seg0; t += 64) {
+                    const T v = pool[seg0 + t];
+                    a.succ[dst0 + t] = v == sentinel<T>() ? -1ll : (int64_t)((uint64_t)v + a.node_base);
+                }
+                if (rep && a.outdeg) a.outdeg[x - a.from] = (int32_t)d;
+            }
+        }
+        __syncthreads();
+        r0 += k;
+    }
+
+    err = wave_or32(err);
+    if (failed) {
+        if (lane == 0) {
+            uint32_t slot = atomicAdd(a.fail_count, 1u);
+            if (slot < a.fail_cap) a.fail_list[slot] = bid;
+        }
+        return;
+    }
+    blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
+    if (lane == 0) {
+        atomicAdd(&a.acc[0], (unsigned long long)blk_arcs);
+        atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
+        atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
+        if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void outdegree_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,
+                                 int coding, int32_t* out, unsigned long long* total) {
+    int64_t x = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t d = 0;
+    if (x < to) {
+        BitCursor cur{graph, offsets[x], limit_byte};
+        d = cur.read_coded(coding, 0, offsets[x + 1]);
+        out[x - from] = (int32_t)d;
+    }
+    if (total) {
+        d = wave_sum64(d);
+        if ((threadIdx.x & 63) == 0 && d) atomicAdd(total, (unsigned long long)d);
+    }
+}
+
+// ---- exclusive scan int32 -> uint64, three phases, 1024 elements per workgroup ----
+constexpr int kScanTile = 1024;
+__global__ void scan_partials(const int32_t* in, int64_t n, uint64_t* partial) {
+    __shared__ uint64_t wsum[4];
+    int64_t i0 = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 4;
+    uint64_t v = 0;
+    for (int t = 0; t < 4; t++) if (i0 + t < n) v += (uint64_t)(uint32_t)in[i0 + t];
+    v = wave_sum64(v);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void scan_partials_serial(uint64_t* partial, int64_t nparts) {
+    // one wavefront: 64-wide chunks with a running carry
+    uint64_t carry = 0;
+    for (int64_t i0 = 0; i0 < nparts; i0 += 64) {
+        int64_t i = i0 + threadIdx.x;
+        uint64_t v = i < nparts ? partial[i] : 0;
+        uint64_t inc = wave_incl_scan64(v);
+        if (i < nparts) partial[i] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+}
+__global__ void scan_final(const int32_t* in, int64_t n, const uint64_t* partial, uint64_t* out) {
+    __shared__ uint64_t wsum[4];
+    int64_t i0 = (int64_t)blockIdx.x * kScanTile + threadIdx.x * 4;
+    uint64_t e[4]; uint64_t v = 0;
+    for (int t = 0; t < 4; t++) { e[t] = (i0 + t < n) ? (uint64_t)(uint32_t)in[i0 + t] : 0; v += e[t]; }
+    uint64_t inc = wave_incl_scan64(v);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint64_t off = partial[blockIdx.x];
+    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) off += wsum[w];
+    uint64_t run = off + inc - v;
+    for (int t = 0; t < 4; t++) { if (i0 + t < n) out[i0 + t] = run; run += e[t]; }
+    if (i0 <= n - 1 && n - 1 < i0 + 4) out[n] = run;     // total at out[n]
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+// ---- plan ----
+__global__ void plan_boundaries_kernel(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first) {
+    uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nb) return;
+    if (j == nb) { first[j] = (uint64_t)n; return; }
+    // first node whose record starts at or after bit j*block_bits
+    const uint64_t target = j * block_bits;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t mid = lo + ((hi - lo) >> 1); if (offsets[mid] < target) lo = mid + 1; else hi = mid; }
+    first[j] = (uint64_t)lo;
+}
+
+__global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first,
+                                 uint32_t nblk, int window, Codings cod, uint32_t* halo, uint64_t* mask) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nblk) return;
+    const int64_t s = (int64_t)first[k];
+    uint64_t m = 0; bool bad = false;
+    if (window > 0 && s > 0) {
+        const int64_t xe = s + window < n ? s + window : n;
+        for (int64_t x = s; x < xe && !bad; x++) {
+            int64_t y = x;
+            for (;;) {                                                       // follow the reference chain of x
+                BitCursor cur{graph, offsets[y], limit_byte};
+                const uint64_t end = offsets[y + 1];
+                uint64_t d = cur.read_coded(cod.outdegree, 0, end);
+                if (d == 0) break;
+                uint64_t r = cur.read_coded(cod.reference, 0, end);
+                if (r == 0 || r > (uint64_t)window || (int64_t)r > y) break;
+                y -= (int64_t)r;
+                if (y < s) {
+                    int64_t dist = s - 1 - y;
+                    if (dist >= kMaxHalo) { bad = true; break; }
+                    m |= 1ull << dist;
+                }
+            }
+        }
+    }
+    halo[k] = bad ? 0xFFFFFFFFu : (m ? 64u - (uint32_t)__builtin_clzll(m) : 0u);
+    mask[k] = m;
+}
+
+// ---- synthetic tiling ----
+__device__ __forceinline__ uint64_t load_bits64(const uint8_t* src, uint64_t bitpos) {
+    const uint8_t* p = src + (bitpos >> 3);
+    uint64_t hi = __builtin_bswap64(*reinterpret_cast<const u64*>(p));
+    unsigned sh = (unsigned)bitpos & 7u;
+    uint64_t w = hi << sh;
+    if (sh) w |= (uint64_t)p[8] >> (8u - sh);
+    return w;
+}
+__global__ void tile_graph_kernel(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_words, uint64_t total_bits) {
+    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= dst_words) return;
+    uint64_t P = w * 64, val = 0;
+    if (P < total_bits) {
+        uint64_t off = P % src_bits, rem = src_bits - off;
+        if (rem >= 64) val = load_bits64(src, off);
+        else {
+            val = load_bits64(src, off) & ~(~0ull >> rem);                   // top `rem` bits
+            unsigned got = (unsigned)rem;
+            while (got < 64) {                                               // src_bits may be < 64
+                uint64_t piece = load_bits64(src, 0);
+                uint64_t take = src_bits < 64u - got ? src_bits : 64u - got;
+                piece &= take >= 64 ? ~0ull : ~(~0ull >> take);
+                val |= piece >> got;
+                got += (unsigned)take;
+            }
+        }
+        if (total_bits - P < 64) val &= ~(~0ull >> (total_bits - P));
+    }
+    reinterpret_cast<uint64_t*>(dst)[w] = __builtin_bswap64(val);
+}
+__global__ void tile_offsets_kernel(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = n * copies;
+    if (i > tot) return;
+    if (i == tot) { dst[i] = (uint64_t)copies * src_bits; return; }
+    int64_t c = i / n, r = i - c * n;
+    dst[i] = (uint64_t)c * src_bits + src[r];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s) {
+    if (nblocks == 0) return;
+    dim3 grid(nblocks), block(64);
+#define BVG_LAUNCH(T, M, S) hipLaunchKernelGGL((decode_kernel<T, M, S>), grid, block, 0, s, a)
+    if (!wide) {
+        if (!materialise) { if (!slow) BVG_LAUNCH(uint32_t, false, false); else BVG_LAUNCH(uint32_t, false, true); }
+        else { if (!slow) BVG_LAUNCH(uint32_t, true, false); else BVG_LAUNCH(uint32_t, true, true); }
+    } else {
+        if (!materialise) { if (!slow) BVG_LAUNCH(uint64_t, false, false); else BVG_LAUNCH(uint64_t, false, true); }
+        else { if (!slow) BVG_LAUNCH(uint64_t, true, false); else BVG_LAUNCH(uint64_t, true, true); }
+    }
+#undef BVG_LAUNCH
+}
+
+void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to, int coding,
+                       int32_t* out, unsigned long long* total, hipStream_t s) {
+    int64_t n = to - from;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(outdegree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, graph, limit_byte, offsets, from, to, coding, out, total);
+}
+
+size_t scan_tmp_elems(int64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 1; }
+
+void launch_exclusive_scan(const int32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s) {
+    int64_t parts = (n + kScanTile - 1) / kScanTile;
+    if (parts == 0) parts = 1;
+    hipLaunchKernelGGL(scan_partials, dim3((unsigned)parts), dim3(256), 0, s, in, n, tmp);
+    hipLaunchKernelGGL(scan_partials_serial, dim3(1), dim3(64), 0, s, tmp, parts);
+    hipLaunchKernelGGL(scan_final, dim3((unsigned)parts), dim3(256), 0, s, in, n, tmp, out);
+}
+
+void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s) {
+    hipLaunchKernelGGL(plan_boundaries_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, s, offsets, n, block_bits, nb, first);
+}
+
+void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first, uint32_t nblk,
+                      int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s) {
+    if (!nblk) return;
+    hipLaunchKernelGGL(plan_halo_kernel, dim3((nblk + 127) / 128), dim3(128), 0, s, graph, limit_byte, offsets, n, first, nblk, window, cod, halo, mask);
+}
+
+void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s) {
+    uint64_t words = dst_bytes / 8;
+    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src, src_bits, dst, words, src_bits * (uint64_t)copies);
+}
+void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s) {
+    int64_t tot = n * copies + 1;
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, n, src_bits, dst, copies);
+}
+
+}  // namespace bvg
