@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — decoded edges/s of a full sequential BVGraph successor scan on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): decoded edges/s of a full sequential successor scan, plus the achieved
+fraction of the HBM-read roofline (algorithmic bytes = size of the .graph stream).
+
+Workload (config.workload): the eu-2015 configuration's synthetic stand-in — a copy-model web graph
+with default BV parameters (window 7, maxRef 3, minInterval 4, zeta_3), generated and compressed on
+the host by the repo's own encoder, then tiled on the device (bvg_tile; BV records are translation
+invariant) until the .graph stream is several GiB, i.e. far beyond the 256 MiB Infinity Cache.
+A "step" is one full scan of every node of the resident graph: successors are decoded, counted and
+checksummed on chip.  With N GPUs each rank holds one such shard of an N-times larger graph (node
+ids shifted by rank * nodes_per_shard, "weak" scaling) and the only collective is one RCCL all-reduce
+of {arcs, checksum}.  Protocol mirrors the reference's SpeedTest (3 warm-up + 10 timed scans).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--base-nodes", type=int, default=1 << 21, help="nodes of the generated base graph")
+    ap.add_argument("--target-gib", type=float, default=8.0, help="size of the tiled .graph stream per GPU")
+    ap.add_argument("--shape", default="eu", choices=["eu", "web", "w0"], help="eu: eu-2015-like (headline); web: cnr-like; w0: window=0 residual-only (config 2)")
+    ap.add_argument("--block-bits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import webgraph_big_amd as W
+    from webgraph_big_amd import tools as T
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = local_rank
+
+    # ---- synthetic input: generate + compress on the host, upload, tile on the device ----
+    t0 = time.time()
+    threads = min(os.cpu_count() or 1, 64)
+    if args.shape == "eu":
+        params, synth, wl = W.default_params(), T.eu_like(), "eu-2015-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"
+    elif args.shape == "web":
+        params, synth, wl = W.default_params(), T.web_like(), "cnr/uk-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"
+    else:
+        params, synth, wl = W.default_params(window_size=0, max_ref_count=0, min_interval_length=0), T.web_like(), "uk-2007-05 re-store stand-in (window=0 maxRef=0, zeta3 residuals only)"
+    st = T.synth_store(args.base_nodes, seed=0, params=params, synth=synth, threads=threads)
+    gen_s = time.time() - t0
+    base_bytes = len(st.graph)
+    copies = max(1, int(args.target_gib * (1 << 30) / max(base_bytes, 1)))
+    copies = min(copies, ((1 << 31) - 1) // args.base_nodes)          # stay on the 32-bit successor kernels
+    t0 = time.time()
+    base = W.BVGraph.from_memory(st.params, st.graph, st.offsets, device=dev)
+    torch.cuda.synchronize()
+    upload_s = time.time() - t0
+    g = base.tile(copies) if copies > 1 else base
+    if args.block_bits:
+        g.set_tuning(block_bits=args.block_bits)
+    n_local = g.num_nodes()
+    g.set_node_base(rank * n_local)                                     # shard `rank` of the N-times larger graph
+    arcs_local = st.stats["arcs"] * copies
+
+    def step():
+        return g.scan()
+
+    r = step()                                                          # correctness gate (untimed)
+    for _ in range(args.warmup):
+        r = step()
+    # correctness gate: arcs must equal the encoder's count; shard 0's first tile must match the CPU oracle below
+    assert r["arcs"] == arcs_local and r["nodes"] == n_local, (r, arcs_local, n_local)
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        r = step()
+        kernel_ms.append(r["kernel_ms"])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    tot_arcs, tot_chk = r["arcs"], r["chk"]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # the only collective of the path: {arcs, checksum} summed mod 2^64 (int64 wrap-around == uint64 sum)
+        red = torch.tensor([np.int64(np.uint64(tot_arcs).astype(np.int64)), np.uint64(tot_chk).astype(np.int64)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        tot_arcs = int(np.int64(red[0].item()).astype(np.uint64)); tot_chk = int(np.int64(red[1].item()).astype(np.uint64))
+    else:
+        tot_arcs, tot_chk = int(tot_arcs), int(tot_chk)
+
+    if rank == 0:
+        edges_per_s = tot_arcs * args.steps / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        gbs = r["graph_bytes"] / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.shape, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "decoded edges/s, full sequential successor scan", "value": edges_per_s, "unit": "edges/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if n_local < (1 << 31) else "u64",
+            "data": "synthetic",
+            "config": {"workload": wl, "nodes_per_gpu": n_local, "arcs_per_gpu": arcs_local, "graph_bytes_per_gpu": r["graph_bytes"],
+                       "bits_per_link": 8.0 * r["graph_bytes"] / arcs_local, "tiles": copies, "base_nodes": args.base_nodes,
+                       "sharding": "node ranges, %d shard(s); RCCL all-reduce of {arcs,chk} only" % args.gpus},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "bvg::decode_kernel<u32,scan>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": r["graph_bytes"], "index_bytes_per_launch": r["index_bytes"]},
+            "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
+            "host": {"generate_s": gen_s, "upload_s": upload_s, "upload_GBps": base_bytes / max(upload_s, 1e-9) / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(st, base, threads)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(st, base_gpu, threads):
+    """The CPU oracle (a C port of the reference's decode path) timed on this box's host cores over the
+    base graph (one tile of the workload), node ranges split as ImmutableGraph.splitNodeIterators does."""
+    from oracle import bvg_oracle as O
+    og = O.Graph.from_memory(O.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    n = st.params.nodes
+    t0 = time.perf_counter(); r1 = og.scan(0, n, threads=threads); tm = time.perf_counter() - t0
+    # also gate the GPU result on it: the first tile of shard 0 must produce the same checksum
+    base_gpu.set_node_base(0)
+    rg = base_gpu.scan()
+    assert (rg["arcs"], rg["chk"]) == (r1["arcs"], r1["chk"]), "GPU scan disagrees with the CPU oracle"
+    # single-thread figure on a bounded sample
+    sample = max(1, min(n, int(n * min(1.0, 10.0 / max(tm * threads, 1e-3)))))
+    t0 = time.perf_counter(); r2 = og.scan(0, sample, threads=1); t1 = time.perf_counter() - t0
+    return {"value": r1["arcs"] / tm, "unit": "edges/s", "cores": threads, "kind": "port",
+            "sample": "base graph (1 tile: %d nodes, %d arcs), %d threads over contiguous node ranges; 1 thread on first %d nodes: %.3g edges/s"
+                      % (n, r1["arcs"], threads, sample, r2["arcs"] / max(t1, 1e-9)),
+            "value_1thread": r2["arcs"] / max(t1, 1e-9), "gpu_matches_oracle": True}
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,9 @@ def test_wide_and_slow_paths_are_bit_exact(W, cnr_csr):
 @pytest.mark.parametrize("params", [
     dict(), dict(window_size=0, max_ref_count=0, min_interval_length=0), dict(window_size=1, max_ref_count=1, min_interval_length=2),
     dict(window_size=3, max_ref_count=10), dict(window_size=16, max_ref_count=2, min_interval_length=0), dict(zeta_k=1), dict(zeta_k=5),
+    dict(outdegree_coding=1, block_coding=1, residual_coding=1, reference_coding=1, block_count_coding=1),      # all delta
+    dict(residual_coding=2, reference_coding=2, block_count_coding=5, block_coding=5),                         # gamma residuals/refs, unary blocks
+    dict(residual_coding=7), dict(residual_coding=3, zeta_k=5),                                                # nibble, Golomb(b=5)
 ])
 def test_synthetic_graphs_match_oracle(W, tools, oracle, params):
     st = tools.synth_store(30000, seed=3, params=W.default_params(**params), threads=4)

@@ -51,7 +51,7 @@ struct Plan {
 struct Shared {
     int device = 0;
     bvg_params p{};
-    uint8_t* d_graph = nullptr; uint64_t nbytes = 0; bool own_graph = false;
+    uint8_t* d_graph = nullptr; uint64_t nbytes = 0; uint64_t padded = 0; bool own_graph = false;
     uint64_t* d_offsets = nullptr; bool own_offsets = false;
     uint64_t total_bits = 0;
     bool wide = false;
@@ -231,16 +231,28 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (hi > pl.nblk) hi = pl.nblk;
     uint32_t nblocks = hi > lo ? hi - lo : 0;
 
+    if (nblocks > g->fail_cap) {                            // every block may fail over to the slow path
+        (void)hipFree(g->d_fail); g->d_fail = nullptr;
+        g->fail_cap = nblocks;
+        HIPCHK(hipMalloc(&g->d_fail, ((size_t)g->fail_cap + 1) * sizeof(uint32_t)));
+    }
     HIPCHK(hipMemsetAsync(g->d_acc, 0, 4 * sizeof(unsigned long long), g->stream));
     HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
 
     DecodeArgs a{};
-    a.graph = sh->d_graph; a.limit_byte = sh->nbytes; a.offsets = sh->d_offsets; a.n = sh->p.nodes;
+    a.graph = sh->d_graph; a.limit_byte = sh->nbytes; a.padded_bytes = sh->padded; a.offsets = sh->d_offsets; a.n = sh->p.nodes;
     a.from = from; a.to = to;
     a.blk_first = pl.d_first; a.blk_halo = pl.d_halo; a.blk_mask = pl.d_mask; a.work_list = nullptr; a.blk_lo = lo;
     a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
     a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap;
+    {   // LDS pool sized to the graph's mean outdegree: a row of 64 lists + the window must fit (bytes bound occupancy)
+        double avg = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
+        uint64_t want = (uint64_t)(avg * 110.0);
+        uint64_t max_elems = wide ? 6144 : 12288;
+        uint64_t pool = std::min<uint64_t>(std::max<uint64_t>((want + 511) & ~511ull, 2048), max_elems);
+        a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)(pool / 4);
+    }
 
     uint32_t launches = 0, slow_blocks = 0;
     std::vector<uint32_t> work;
@@ -253,6 +265,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     HIPCHK(hipStreamSynchronize(g->stream));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
     double kernel_ms = ms;
+    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] fast launch: %u blocks, %.3f ms\n", nblocks, ms);
 
     if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = lo + i; }
     else {
@@ -293,6 +306,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         HIPCHK(hipStreamSynchronize(g->stream));
         HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
         kernel_ms += ms;
+        if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] slow launch: %zu blocks, pool %llu elems, %.3f ms\n", work.size(), (unsigned long long)pool_elems, ms);
         uint32_t nfail = 0;
         HIPCHK(hipMemcpy(&nfail, g->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost));
         std::vector<uint32_t> next(nfail);
@@ -328,9 +342,10 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
     sh->device = device; sh->p = *p; sh->nbytes = nbytes;
     sh->wide = p->nodes > (int64_t)0x7FFFFFFF;
     const int64_t n = p->nodes;
-    if (d_graph_in) { sh->d_graph = (uint8_t*)d_graph_in; sh->own_graph = false; }
+    if (d_graph_in) { sh->d_graph = (uint8_t*)d_graph_in; sh->own_graph = false; sh->padded = ((nbytes + 15) & ~15ull) + 16; }
     else {
         uint64_t padded = ((nbytes + 15) & ~15ull) + kPad;
+        sh->padded = padded;
         HIPCHK(hipMalloc(&sh->d_graph, padded));
         sh->own_graph = true;
         HIPCHK(hipMemset(sh->d_graph, 0, padded));

@@ -33,8 +33,13 @@ struct BitCursor {
     const uint8_t* base;
     uint64_t pos;          // absolute bit position
     uint64_t limit_byte;
+    // Optional LDS window over the stream: win[i] = big-endian dword i of the staged bytes, the first
+    // staged bit being absolute bit win_bit0.  Positions outside it fall back to global memory.
+    const uint32_t* win = nullptr;
+    uint64_t win_bit0 = 0;
+    uint32_t win_bits = 0;
 
-    __device__ __forceinline__ uint64_t peek() const {
+    __device__ __forceinline__ uint64_t peek_global() const {
         uint64_t byte = pos >> 3;
         byte = byte < limit_byte ? byte : limit_byte;
         const uint8_t* p = base + byte;
@@ -44,6 +49,16 @@ struct BitCursor {
         uint64_t w = hi << sh;
         if (sh) w |= (uint64_t)p[8] >> (8u - sh);
         return w;
+    }
+    __device__ __forceinline__ uint64_t peek() const {
+        const uint64_t rel = pos - win_bit0;
+        if (rel + 96 <= (uint64_t)win_bits) {                 // (wraps to huge when pos < win_bit0)
+            const uint32_t wi = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31u;
+            const uint32_t a = win[wi], b = win[wi + 1], c = win[wi + 2];
+            const uint64_t ab = ((uint64_t)a << 32) | b;
+            return sh ? (ab << sh) | (uint64_t)(c >> (32u - sh)) : ab;
+        }
+        return peek_global();
     }
     __device__ __forceinline__ void skip(unsigned n) { pos += n; }
 

@@ -8,12 +8,13 @@
 namespace bvg {
 
 // LDS geometry of the fast (one wavefront per node block) decode kernel.
-constexpr int kRing = 256;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
-constexpr int kMaxWindow = 128;      // larger windows take the slow path only if a block needs it; beyond: unsupported
+constexpr int kRing = 128;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
+constexpr int kMaxWindow = 64;       // larger windows take the slow path only if a block needs it; beyond: unsupported
 constexpr int kMaxHalo = 64;         // halo nodes a block may need from before its first node (one row)
 
 struct DecodeArgs {
     const uint8_t* graph; uint64_t limit_byte;
+    uint64_t padded_bytes;              // readable bytes of `graph` (multiple of 16)
     const uint64_t* offsets;            // n+1 bit positions
     int64_t n;
     int64_t from, to;                   // only nodes in [from,to) are reported
@@ -33,6 +34,8 @@ struct DecodeArgs {
     uint32_t* fail_list; uint32_t* fail_count; uint32_t fail_cap;
     // slow-path pools (global memory), per workgroup
     void* gpool; uint64_t gpool_elems; void* gscr; uint64_t gscr_elems;
+    // fast path: LDS pool / scratch sizes in elements (dynamic shared memory)
+    uint32_t lds_pool_elems, lds_scr_elems;
 };
 
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);

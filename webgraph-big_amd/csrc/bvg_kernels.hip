@@ -22,15 +22,15 @@
 // kernel instantiated over a global-memory pool (the slow path).
 #include "bvg_kernels.h"
 
+#include <type_traits>
+
 namespace bvg {
 
 namespace {
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 
-template <typename T> struct PoolCfg;
-template <> struct PoolCfg<uint32_t> { static constexpr uint32_t pool = 3072, scr = 768; };
-template <> struct PoolCfg<uint64_t> { static constexpr uint32_t pool = 1536, scr = 384; };
+constexpr uint32_t kStageBytes = 4096;     // LDS window over the .graph stream (one default block)
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
@@ -43,12 +43,25 @@ __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v) {
     return v;
 }
 
-template <typename T, bool MAT, bool SLOW>
+// GEN = false: the file uses BVGraph's default codings (gamma outdegrees / block counts / blocks, unary
+// references, zeta_k residuals — BVGraph.java:527-542), decoded by straight-line code; GEN = true:
+// any legal combination of compressionflags, dispatched per field (grid-uniform branches).
+template <bool GEN> struct Rd {
+    static __device__ __forceinline__ uint64_t outdegree(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.outdegree, 0, g); return c.read_gamma(g); }
+    static __device__ __forceinline__ uint64_t reference(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.reference, 0, g); return c.read_unary(g); }
+    static __device__ __forceinline__ uint64_t block_count(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.block_count, 0, g); return c.read_gamma(g); }
+    static __device__ __forceinline__ uint64_t block(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.block, 0, g); return c.read_gamma(g); }
+    static __device__ __forceinline__ uint64_t residual(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.residual, (unsigned)k.zeta_k, g); return c.read_zeta((unsigned)k.zeta_k, g); }
+};
+
+template <typename T, bool MAT, bool SLOW, bool GEN>
 __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
+    typedef Rd<GEN> R;
     constexpr uint32_t RM = kRing - 1;
-    __shared__ T lds_pool[SLOW ? 1 : PoolCfg<T>::pool];
-    __shared__ T lds_scr[SLOW ? 1 : PoolCfg<T>::scr];
-    __shared__ uint64_t nd_base[kRing];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // fast path: pool then scratch
+    __shared__ uint32_t stage[kStageBytes / 4];
+    typedef typename std::conditional<SLOW, uint64_t, uint32_t>::type idx_t;
+    __shared__ idx_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
     __shared__ uint32_t produced[64];
     __shared__ uint32_t scr_used;
@@ -62,15 +75,16 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     const int W = a.window;
     const int64_t rep_lo = s > a.from ? s : a.from, rep_hi = e < a.to ? e : a.to;
 
-    T* const pool = SLOW ? reinterpret_cast<T*>(a.gpool) + (uint64_t)blockIdx.x * a.gpool_elems : lds_pool;
-    T* const scr = SLOW ? reinterpret_cast<T*>(a.gscr) + (uint64_t)blockIdx.x * a.gscr_elems : lds_scr;
-    const uint64_t CAP = SLOW ? a.gpool_elems : PoolCfg<T>::pool;
-    const uint64_t SCR = SLOW ? a.gscr_elems : PoolCfg<T>::scr;
+    T* const pool = SLOW ? reinterpret_cast<T*>(a.gpool) + (uint64_t)blockIdx.x * a.gpool_elems : reinterpret_cast<T*>(dyn_lds);
+    T* const scr = SLOW ? reinterpret_cast<T*>(a.gscr) + (uint64_t)blockIdx.x * a.gscr_elems : reinterpret_cast<T*>(dyn_lds) + a.lds_pool_elems;
+    const uint64_t CAP = SLOW ? a.gpool_elems : a.lds_pool_elems;
+    const uint64_t SCR = SLOW ? a.gscr_elems : a.lds_scr_elems;
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
     __syncthreads();
 
     uint64_t pool_used = 0;
+    uint64_t stg_bit0 = 0; uint32_t stg_bits = 0;             // staged window (wave-uniform)
     uint64_t blk_arcs = 0, blk_chk = 0, blk_nodes = 0;
     unsigned err = 0;
     bool failed = false;
@@ -82,14 +96,29 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
         const bool in_range = x < e;
         const uint64_t hbit = x < s ? (uint64_t)(s - 1 - x) : 0;
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
-        BitCursor cur{a.graph, 0, a.limit_byte};
-        uint64_t rec_end = 0;
-        uint32_t d = 0;
-        if (needed) {
-            cur.pos = a.offsets[x];
-            rec_end = a.offsets[x + 1];
-            d = (uint32_t)cur.read_coded(a.cod.outdegree, 0, rec_end);      // readOutdegree, BVG:654-660
+        uint64_t off_x = 0, rec_end = 0;
+        if (in_range) { off_x = a.offsets[x]; rec_end = a.offsets[x + 1]; }
+        {   // (re)stage the LDS window when this row's records are not covered by it
+            const int64_t left = e - r0;
+            const uint64_t row_lo = __shfl(off_x, 0, 64);
+            const uint64_t row_hi = __shfl(rec_end, left >= 64 ? 63 : (int)left - 1, 64);
+            if (!(row_lo >= stg_bit0 && row_hi + 64 <= stg_bit0 + stg_bits)) {
+                __syncthreads();
+                const uint64_t b0 = (row_lo >> 3) & ~15ull;
+                uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
+                if (nb > kStageBytes) nb = kStageBytes;
+                for (uint32_t c = lane; c < (uint32_t)(nb >> 4); c += 64) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
+                    uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
+                    *reinterpret_cast<uint4*>(&stage[c << 2]) = w;
+                }
+                stg_bit0 = b0 << 3; stg_bits = (uint32_t)(nb << 3);
+                __syncthreads();
+            }
         }
+        BitCursor cur{a.graph, off_x, a.limit_byte, stage, stg_bit0, stg_bits};
+        uint32_t d = 0;
+        if (needed) d = (uint32_t)R::outdegree(cur, a.cod, rec_end);          // readOutdegree, BVG:654-660
         // how many leading lanes fit in the pool?
         uint64_t dclamp = d > CAP ? CAP + 1 : d;
         uint64_t incl = wave_incl_scan64(dclamp);
@@ -107,7 +136,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 if (src != dst)
                     for (uint64_t t = lane; t < len; t += 64) { T v = pool[src + t]; pool[dst + t] = v; }
             }
-            if (livelane) nd_base[(uint64_t)y & RM] = nbase;
+            if (livelane) nd_base[(uint64_t)y & RM] = (idx_t)nbase;
             pool_used = __shfl(nincl, 63, 64);
             avail = CAP - pool_used;
             __syncthreads();
@@ -121,7 +150,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
         if (k == 0) { failed = true; break; }                                // first node alone overflows the pool
         const bool act = needed && lane < k;
         const uint64_t base = pool_used + (incl - dclamp);
-        if (act) { nd_base[(uint64_t)x & RM] = base; nd_d[(uint64_t)x & RM] = d; }
+        if (act) { nd_base[(uint64_t)x & RM] = (idx_t)base; nd_d[(uint64_t)x & RM] = d; }
         pool_used += __shfl(incl, (int)k - 1, 64);
         if (lane == 0) scr_used = 0;
         produced[lane] = act ? 0u : kInf;
@@ -133,20 +162,20 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
         bool overflow = false;
         if (act && d > 0) {
             if (W > 0) {                                                     // BVG:1015
-                uint64_t r = cur.read_coded(a.cod.reference, 0, rec_end);   // readReference, BVG:692-703
+                uint64_t r = R::reference(cur, a.cod, rec_end);             // readReference, BVG:692-703
                 if (r > (uint64_t)W || (int64_t)r > x) { err |= ERR_REF_RANGE; r = 0; }
                 ref = (uint32_t)r;
             }
             int64_t extra = d;
             if (ref > 0) {                                                   // BVG:1020-1032
-                uint64_t nb = cur.read_coded(a.cod.block_count, 0, rec_end);
+                uint64_t nb = R::block_count(cur, a.cod, rec_end);
                 if (nb > rec_end - (cur.pos < rec_end ? cur.pos : rec_end) + 1) { err |= ERR_OVERRUN; nb = 0; }
                 bc = (uint32_t)nb;
                 sb = atomicAdd(&scr_used, bc);
                 if (sb + bc > SCR) { overflow = true; bc = 0; }
                 int64_t copied = 0, tot = 0;
                 for (uint32_t i = 0; i < bc; i++) {
-                    uint64_t b = cur.read_coded(a.cod.block, 0, rec_end) + (i ? 1 : 0);
+                    uint64_t b = R::block(cur, a.cod, rec_end) + (i ? 1 : 0);
                     scr[sb + i] = (T)b;
                     tot += (int64_t)b;
                     if (!(i & 1)) copied += (int64_t)b;
@@ -176,10 +205,10 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
             nres = (uint32_t)extra;
             if (nres > 0 && !overflow) {                                     // ResidualLongIterator, BVG:902-935
                 T* tail = pool + base + d - nres;
-                int64_t r = x + nat2int(cur.read_coded(a.cod.residual, a.cod.zeta_k, rec_end));
+                int64_t r = x + nat2int(R::residual(cur, a.cod, rec_end));
                 tail[0] = (T)r;
                 for (uint32_t t = 1; t < nres; t++) {
-                    r += (int64_t)cur.read_coded(a.cod.residual, a.cod.zeta_k, rec_end) + 1;
+                    r += (int64_t)R::residual(cur, a.cod, rec_end) + 1;
                     tail[t] = (T)r;
                     if (cur.pos > rec_end) { err |= ERR_OVERRUN; break; }
                 }
@@ -428,7 +457,12 @@ __global__ void tile_offsets_kernel(const uint64_t* src, int64_t n, uint64_t src
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s) {
     if (nblocks == 0) return;
     dim3 grid(nblocks), block(64);
-#define BVG_LAUNCH(T, M, S) hipLaunchKernelGGL((decode_kernel<T, M, S>), grid, block, 0, s, a)
+    const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
+                       a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
+    const size_t dyn = slow ? 0 : (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4);
+#define BVG_LAUNCH2(T, M, S) do { if (gen) hipLaunchKernelGGL((decode_kernel<T, M, S, true>), grid, block, dyn, s, a); \
+                                  else hipLaunchKernelGGL((decode_kernel<T, M, S, false>), grid, block, dyn, s, a); } while (0)
+#define BVG_LAUNCH(T, M, S) BVG_LAUNCH2(T, M, S)
     if (!wide) {
         if (!materialise) { if (!slow) BVG_LAUNCH(uint32_t, false, false); else BVG_LAUNCH(uint32_t, false, true); }
         else { if (!slow) BVG_LAUNCH(uint32_t, true, false); else BVG_LAUNCH(uint32_t, true, true); }
@@ -436,6 +470,7 @@ void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materi
         if (!materialise) { if (!slow) BVG_LAUNCH(uint64_t, false, false); else BVG_LAUNCH(uint64_t, false, true); }
         else { if (!slow) BVG_LAUNCH(uint64_t, true, false); else BVG_LAUNCH(uint64_t, true, true); }
     }
+#undef BVG_LAUNCH2
 #undef BVG_LAUNCH
 }
 

@@ -30,7 +30,7 @@ class SynthParams(C.Structure):
 
 def web_like(**kw):
     """Copy-model parameters tuned towards cnr-2000's arc provenance."""
-    sp = SynthParams(p_empty=0.2, mean_deg=18.0, tail_alpha=1.8, max_deg=3000, p_copy=0.9, keep_run=12.0, skip_run=1.5,
+    sp = SynthParams(p_empty=0.2, mean_deg=16.0, tail_alpha=2.5, max_deg=3000, p_copy=0.9, keep_run=12.0, skip_run=1.5,
                      p_interval=0.4, interval_len=8.0, local_gap=5.0, p_far=0.04, window=7, pad=0, extra_mean=1.5)
     for k, v in kw.items():
         setattr(sp, k, v)
@@ -40,7 +40,7 @@ def web_like(**kw):
 def eu_like(**kw):
     """Denser, more copy-heavy variant (eu-2015-shaped: average outdegree ~60-90, ~2.5 bits/link)."""
     return web_like(**dict(dict(p_copy=0.88, keep_run=25.0, skip_run=2.0, extra_mean=4.0, mean_deg=90.0, p_interval=0.5,
-                                interval_len=20.0, max_deg=20000, local_gap=6.0, p_far=0.03), **kw))
+                                interval_len=20.0, max_deg=20000, local_gap=6.0, p_far=0.03, tail_alpha=2.7), **kw))
 
 
 def build(force=False):
