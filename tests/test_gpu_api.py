@@ -1,0 +1,186 @@
+"""GPU: the host-side mirror of the reference API (ImmutableGraph / NodeIterator / LazyLongIterator)
+and the auxiliary C-ABI entry points, checked against the oracle.  Follows WebGraphTestCase.assertGraph
+(test/it/unimi/dsi/big/webgraph/WebGraphTestCase.java:106-199)."""
+import numpy as np
+import pytest
+
+from conftest import CNR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(W, tools, oracle):
+    st = tools.synth_store(5000, seed=2, chunk_nodes=1024, threads=2)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    deg, succ = og.decode_range(0, 5000)
+    cum = np.concatenate([[0], np.cumsum(deg)])
+    lists = [succ[cum[i]:cum[i + 1]] for i in range(5000)]
+    return g, og, lists, st
+
+
+def test_assert_graph_contract(W, small):
+    g, og, lists, st = small
+    n = g.num_nodes()
+    it = g.node_iterator()
+    with pytest.raises(W.IllegalStateException):
+        it.outdegree()                                                      # BVGraph.java:1207
+    arcs = 0
+    for x in range(n):
+        assert it.has_next()
+        assert it.next_long() == x
+        d = it.outdegree()
+        assert d == len(lists[x])
+        assert np.array_equal(it.successor_array(), lists[x])
+        li = it.successors()
+        assert [li.next_long() for _ in range(d)] == lists[x].tolist()
+        assert li.next_long() == -1 and li.next_long() == -1               # WebGraphTestCase.java:125
+        arcs += d
+    assert not it.has_next()
+    with pytest.raises(W.NoSuchElementException):
+        it.next_long()                                                      # BVGraph.java:1165
+    assert arcs == g.num_arcs()                                             # WebGraphTestCase.java:140
+
+
+@pytest.mark.parametrize("start", [0, 1, 6, 7, 8, 63, 64, 65, 1023, 1024, 1025, 4999, 5000])
+def test_node_iterator_from_every_kind_of_start(small, start):
+    """WebGraphTestCase.java:151-180: nodeIterator(s) agrees with random access for all later nodes."""
+    g, og, lists, st = small
+    it = g.node_iterator(start)
+    for x in range(start, min(start + 200, g.num_nodes())):
+        assert it.next_long() == x
+        assert np.array_equal(it.successor_array(), lists[x])
+        assert g.outdegree(x) == len(lists[x])
+    if start == g.num_nodes():
+        assert not it.has_next()
+
+
+def test_copy_and_split_node_iterators(small):
+    g, og, lists, st = small
+    it = g.node_iterator(10)
+    it.next_long(); it.next_long()
+    c = it.copy(40)                                                         # NodeIterator.copy(upperBound), BVGraph.java:1223-1229
+    seen = [x for x in c]
+    assert seen == list(range(12, 40))
+    parts = g.split_node_iterators(3)                                       # ImmutableGraph.java:405-436
+    got = []
+    for p in parts:
+        for x in p:
+            got.append(x)
+            assert np.array_equal(p.successor_array(), lists[x])
+    assert got == list(range(g.num_nodes()))
+    g2 = g.copy()                                                           # flyweight, BVGraph.java:553-578
+    assert np.array_equal(g2.successor_array(77), lists[77])
+
+
+def test_errors_map_to_reference_exceptions(W, small):
+    g, og, lists, st = small
+    n = g.num_nodes()
+    for bad in (-1, n):
+        with pytest.raises(W.IllegalArgumentException):
+            g.outdegree(bad)                                                # BVGraph.java:823
+        with pytest.raises(W.IllegalArgumentException):
+            g.successors(bad)                                               # BVGraph.java:863
+    with pytest.raises(W.IllegalArgumentException):
+        g.node_iterator(n + 1)                                              # BVGraph.java:1128
+    with pytest.raises(W.IllegalArgumentException):
+        g.decode_range(5, 4)
+    with pytest.raises(W.UnsupportedOperationException):
+        W.BVGraph.from_memory(W.default_params(nodes=1, outdegree_coding=W.ZETA), b"\x80", np.array([0, 1], dtype=np.uint64))   # BVG:658
+    with pytest.raises(W.IllegalStateException):
+        W.BVGraph.from_memory(W.default_params(nodes=1), b"\x80", None)    # no offsets: BVGraph.java:832,1136
+
+
+def test_offsets_and_outdegrees_by_products(small):
+    g, og, lists, st = small
+    assert np.array_equal(g.offsets(), st.offsets)
+    assert np.array_equal(g.outdegrees(), np.array([len(l) for l in lists], dtype=np.int32))
+    b = g.split_by_bits(4)
+    assert b[0] == 0 and b[-1] == g.num_nodes() and all(b[i] <= b[i + 1] for i in range(4))
+    bits = np.diff(st.offsets[b].astype(np.int64))
+    assert bits.max() - bits.min() < int(st.offsets[-1]) // 4 // 4 + 20000     # roughly equal compressed size
+
+
+def test_tile_is_a_translated_concatenation(W, small, oracle):
+    """bvg_tile: K copies of the stream are the graph shifted by j*n (translation invariance)."""
+    g, og, lists, st = small
+    n = g.num_nodes()
+    t = g.tile(3)
+    assert t.num_nodes() == 3 * n and t.num_arcs() == 3 * g.num_arcs()
+    deg, succ = t.decode_range(n - 5, 2 * n + 5)
+    exp = [lists[x] for x in range(n - 5, n)] + [l + n for l in lists] + [lists[x] + 2 * n for x in range(5)]
+    assert deg.tolist() == [len(l) for l in exp]
+    assert np.array_equal(succ, np.concatenate(exp))
+    r = t.scan()
+    want_chk = sum(og.scan(0, n, node_base=j * n)["chk"] for j in range(3)) % (1 << 64)
+    assert r["arcs"] == 3 * g.num_arcs() and r["chk"] == want_chk
+    # node_base: the shard semantics used by bench.py --gpus N
+    g.set_node_base(7 * n)
+    assert g.scan()["chk"] == og.scan(0, n, node_base=7 * n)["chk"]
+    d2, s2 = g.decode_range(10, 20)
+    assert np.array_equal(s2, np.concatenate([lists[x] for x in range(10, 20)]) + 7 * n)
+    g.set_node_base(0)
+
+
+def test_scan_subranges_add_up(small):
+    g, og, lists, st = small
+    whole = g.scan()
+    parts = [g.scan(a, b) for a, b in [(0, 1), (1, 777), (777, 778), (778, 4096), (4096, 5000)]]
+    assert sum(p["arcs"] for p in parts) == whole["arcs"]
+    assert sum(p["chk"] for p in parts) % (1 << 64) == whole["chk"]
+    for (a, b), p in zip([(0, 1), (1, 777)], parts):
+        o = og.scan(a, b)
+        assert (p["arcs"], p["chk"], p["nodes"]) == (o["arcs"], o["chk"], o["nodes"])
+
+
+def test_corrupt_streams_fail_cleanly(W, small):
+    """A damaged .graph must end in an error status or a (wrong) result — never a hang or a fault."""
+    g, og, lists, st = small
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        bad = st.graph.copy()
+        for pos in rng.integers(0, len(bad), 40):
+            bad[pos] ^= 1 << int(rng.integers(0, 8))
+        h = W.BVGraph.from_memory(st.params, bad, st.offsets)
+        try:
+            h.scan()
+        except (W.EOFException, W.IllegalStateException):
+            pass
+        h.close()
+    # offsets that disagree with the stream are detected (SURVEY A.6 self-check)
+    off = st.offsets.copy(); off[100:200] += 3
+    h = W.BVGraph.from_memory(st.params, st.graph, off)
+    with pytest.raises((W.EOFException, W.IllegalStateException)):
+        h.scan()
+
+
+def test_giant_node_takes_the_slow_path_and_stays_exact(W, tools, oracle):
+    """A list far larger than the LDS pool (cf. BVGraphSlowTest's 2^30-outdegree node, scaled down)."""
+    rng = np.random.default_rng(9)
+    big = np.unique(rng.integers(0, 3_000_000, 150_000))
+    lists = [[1, 2], big.tolist(), big[::2].tolist(), [5], list(range(100, 70_000)), []] + [[i, i + 1] for i in range(6, 200)]
+    st = tools.store(lists, W.default_params())
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    deg, succ = g.decode_range(0, len(lists))
+    assert deg.tolist() == [len(l) for l in lists]
+    assert np.array_equal(succ, np.concatenate([np.asarray(l, dtype=np.int64) for l in lists if len(l)]))
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    r, o = g.scan(), og.scan()
+    assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"]) and r["slow_blocks"] >= 1
+
+
+def test_wide_ids_beyond_32_bits(W, tools, oracle):
+    """Successor ids above 2^32 (the 'big' in webgraph-big): the 64-bit kernels are selected by node count."""
+    n = 3000
+    off, adj = tools.synth_adjacency(n, seed=4, chunk_nodes=1024)
+    st = tools.store((off, adj), W.default_params(), chunk_nodes=1024)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    base = (1 << 33) + 12345
+    g.set_node_base(base)
+    deg, succ = g.decode_range(0, n)
+    assert np.array_equal(succ, adj + base)
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]
+    g.set_tuning(force_wide=True)
+    assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]

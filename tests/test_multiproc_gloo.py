@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py — node-range shards with a node-id base and
+the single all-reduce of {arcs, checksum} — reproduces the checksum of the whole (tiled) graph.
+The per-shard scans run on the CPU oracle here (there is no GPU in this container); on the GPU box
+the same helper reduces the HIP results over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, seed, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    import webgraph_big_amd as W
+    from webgraph_big_amd import tools as T, shard as S
+    from oracle import bvg_oracle as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    st = T.synth_store(n, seed=seed, chunk_nodes=2048, threads=2)       # every rank holds the same shard bytes (weak scaling)
+    og = O.Graph.from_memory(O.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    r = og.scan(0, n, node_base=rank * n)                               # shard `rank` of the world-times larger graph
+    arcs, chk = S.allreduce_scan(r["arcs"], r["chk"])
+    tmax = S.allreduce_max(float(rank))
+    if rank == 0:
+        q.put((arcs, chk, tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_scan_matches_whole_graph(W, tools, oracle):
+    import torch.multiprocessing as mp
+    n, seed, world = 6000, 21, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, q)) for r in range(world)]
+    for p in procs: p.start()
+    arcs, chk, tmax = q.get(timeout=120)
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert tmax == 1.0
+    # the whole graph: `world` translated copies of the shard, stored explicitly and scanned in one piece
+    off, adj = tools.synth_adjacency(n, seed=seed, chunk_nodes=2048)
+    deg = np.diff(off).astype(np.int64)
+    big_adj = np.concatenate([adj + j * n for j in range(world)])
+    big_off = np.concatenate([[0], np.cumsum(np.tile(deg, world))]).astype(np.uint64)
+    st = tools.store((big_off, big_adj), W.default_params(), chunk_nodes=2048)
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    whole = og.scan()
+    assert (arcs, chk) == (whole["arcs"], whole["chk"])
+
+
+def test_split_nodes_matches_reference_rule(W):
+    from webgraph_big_amd import shard as S
+    assert S.split_nodes(10, 3) == [(0, 4), (4, 8), (8, 10)]
+    assert S.split_nodes(3, 5) == [(0, 1), (1, 2), (2, 3), (3, 3), (3, 3)]     # extras are empty (NodeIterator.EMPTY)
+    assert S.split_nodes(0, 2) == [(0, 0), (0, 0)]
+    assert S.i64_to_u64(S.u64_to_i64((1 << 64) - 5)) == (1 << 64) - 5
