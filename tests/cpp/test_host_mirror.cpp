@@ -1,0 +1,62 @@
+// C++ twin of BVGraphTest.testLarge / WebGraphTestCase.assertGraph over the host mirror
+// (webgraph-big_amd/host/bvgraph.hpp -> C ABI -> HIP kernels).  Prints what it measured; the pytest
+// wrapper (tests/test_gpu_cpp_mirror.py) compares with the oracle / golden.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "../../webgraph-big_amd/host/bvgraph.hpp"
+
+using namespace webgraph;
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s basename\n", argv[0]); return 2; }
+    try {
+        auto g = BVGraph::load(argv[1]);
+        const int64_t n = g->numNodes();
+        uint64_t arcs = 0, chk = 0;
+        auto it = g->nodeIterator();
+        bool threw = false;
+        try { it.outdegree(); } catch (const std::logic_error&) { threw = true; }          // IllegalStateException before nextLong
+        if (!threw) { printf("FAIL no IllegalStateException\n"); return 1; }
+        while (it.hasNext()) {
+            int64_t x = it.nextLong();
+            int64_t d = it.outdegree();
+            auto s = it.successors();
+            int64_t prev = -1;
+            for (int64_t j = 0; j < d; j++) {
+                int64_t y = s.nextLong();
+                if (y <= prev) { printf("FAIL not increasing at node %lld\n", (long long)x); return 1; }
+                prev = y;
+                chk += bvg_arc_mix((uint64_t)x, (uint64_t)y);
+            }
+            if (s.nextLong() != -1) { printf("FAIL no -1 after %lld successors\n", (long long)d); return 1; }
+            arcs += (uint64_t)d;
+        }
+        threw = false;
+        try { it.nextLong(); } catch (const std::out_of_range&) { threw = true; }            // NoSuchElementException
+        if (!threw) { printf("FAIL no NoSuchElementException\n"); return 1; }
+        // random access agrees with the sequential scan on a few nodes; copies are independent
+        auto g2 = g->copy();
+        auto it2 = g2->nodeIterator(n / 2);
+        for (int i = 0; i < 50 && it2.hasNext(); i++) {
+            int64_t x = it2.nextLong();
+            auto ra = g->successorBigArray(x);
+            if ((int64_t)ra.size() != it2.outdegree() || g->outdegree(x) != it2.outdegree()) { printf("FAIL outdegree mismatch\n"); return 1; }
+            const int64_t* sa = it2.successorBigArray();
+            for (size_t j = 0; j < ra.size(); j++) if (ra[j] != sa[j]) { printf("FAIL successor mismatch\n"); return 1; }
+        }
+        threw = false;
+        try { g->outdegree(n); } catch (const std::invalid_argument&) { threw = true; }
+        if (!threw) { printf("FAIL no IllegalArgumentException\n"); return 1; }
+        uint64_t parts = 0;
+        for (auto& p : g->splitNodeIterators(4)) while (p.hasNext()) { p.nextLong(); parts += (uint64_t)p.outdegree(); }
+        bvg_scan_result r = g->scan();
+        printf("OK nodes=%lld arcs=%llu chk=%016llx scan_arcs=%llu scan_chk=%016llx split_arcs=%llu\n", (long long)n, (unsigned long long)arcs,
+               (unsigned long long)chk, (unsigned long long)r.arcs, (unsigned long long)r.chk, (unsigned long long)parts);
+        return 0;
+    } catch (const std::exception& e) {
+        printf("FAIL exception: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,23 @@
+"""GPU: the C++ host mirror (webgraph-big_amd/host/bvgraph.hpp) driven by a compiled C++ program."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, CNR
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_mirror_scans_cnr2000(W, oracle):
+    exe = os.path.join(ROOT, "webgraph-big_amd", "lib", "test_host_mirror")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "webgraph-big_amd"), "lib/test_host_mirror"])
+    out = subprocess.run([exe, CNR], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"OK nodes=(\d+) arcs=(\d+) chk=([0-9a-f]+) scan_arcs=(\d+) scan_chk=([0-9a-f]+) split_arcs=(\d+)", out.stdout)
+    assert m, out.stdout
+    o = oracle.Graph.load(CNR).scan()
+    assert int(m.group(1)) == 325557
+    assert int(m.group(2)) == int(m.group(4)) == int(m.group(6)) == o["arcs"] == 3216152
+    assert int(m.group(3), 16) == int(m.group(5), 16) == o["chk"]
