@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--shape", default="eu", choices=["eu", "web", "w0"], help="eu: eu-2015-like (headline); web: cnr-like; w0: window=0 residual-only (config 2)")
     ap.add_argument("--block-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream", action="store_true", help="use the experimental streaming data-flow kernel as tier 0 (A/B)")
+    ap.add_argument("--grab-threshold", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,8 +81,8 @@ def main():
     torch.cuda.synchronize()
     upload_s = time.time() - t0
     g = base.tile(copies) if copies > 1 else base
-    if args.block_bits:
-        g.set_tuning(block_bits=args.block_bits)
+    if args.block_bits or args.stream or args.grab_threshold:
+        g.set_tuning(block_bits=args.block_bits, stream=args.stream, grab_threshold=args.grab_threshold)
     n_local = g.num_nodes()
     g.set_node_base(rank * n_local)                                     # shard `rank` of the N-times larger graph
     arcs_local = st.stats["arcs"] * copies

@@ -134,7 +134,7 @@ typedef struct bvg_tuning {
     uint32_t block_bits;     /* target compressed bits per node block (one wavefront each); 0 = default */
     uint32_t force_wide;     /* 1 = use the 64-bit successor kernels even when nodes < 2^31 */
     uint32_t force_slow;     /* 1 = route every block through the global-memory slow path (tests) */
-    uint32_t reserved;
+    uint32_t reserved;       /* low byte 2 = experimental streaming kernel as tier 0; bits 8.. = its grab threshold */
 } bvg_tuning;
 int bvg_set_tuning(bvg_graph* g, const bvg_tuning* t);
 

@@ -70,6 +70,7 @@ struct bvg_graph {
     uint32_t fail_cap = 0;
     uint64_t node_base = 0;
     bvg_tuning tun{};
+    void* slow_ws = nullptr; uint64_t slow_ws_bytes = 0;   // tier-2 (global-memory) pools, kept between calls
 };
 
 namespace {
@@ -246,78 +247,114 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
     a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap;
-    {   // LDS pool sized to the graph's mean outdegree: a row of 64 lists + the window must fit (bytes bound occupancy)
-        double avg = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
-        uint64_t want = (uint64_t)(avg * 110.0);
-        uint64_t max_elems = wide ? 6144 : 12288;
-        uint64_t pool = std::min<uint64_t>(std::max<uint64_t>((want + 511) & ~511ull, 2048), max_elems);
-        a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)(pool / 4);
+    const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
+    a.grab_threshold = (g->tun.reserved >> 8) ? (g->tun.reserved >> 8) : 40;
+    const size_t esz = wide ? 8 : 4;
+    const double avg = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
+    {   // stream window: ~1.5 rows of records, 1..4 KiB (LDS bytes bound occupancy, and occupancy bounds throughput)
+        const double bits_per_node = sh->p.nodes > 0 ? (double)sh->total_bits / (double)sh->p.nodes : 64.0;
+        uint32_t words = 256;
+        while (words < 1024 && (double)words * 32.0 < bits_per_node * 64.0 * 1.5) words *= 2;
+        a.lds_stage_words = words;
     }
+    if (getenv("BVG_STAGE")) a.lds_stage_words = (uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u;
 
     uint32_t launches = 0, slow_blocks = 0;
+    double kernel_ms = 0;
     std::vector<uint32_t> work;
-    HIPCHK(hipEventRecord(g->ev0, g->stream));
-    if (nblocks && !g->tun.force_slow) {
-        launch_decode(a, nblocks, wide, materialise, false, g->stream);
-        launches++;
-    }
-    HIPCHK(hipEventRecord(g->ev1, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
-    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
-    double kernel_ms = ms;
-    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] fast launch: %u blocks, %.3f ms\n", nblocks, ms);
-
-    if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = lo + i; }
-    else {
+    uint32_t* d_work = nullptr;
+    auto fetch_failures = [&](std::vector<uint32_t>& out) -> int {
         uint32_t nfail = 0;
         HIPCHK(hipMemcpy(&nfail, g->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        if (nfail > g->fail_cap) return BVG_E_NOMEM;     // pathological: > 64K oversized blocks
-        work.resize(nfail);
-        if (nfail) HIPCHK(hipMemcpy(work.data(), g->d_fail + 1, nfail * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    }
+        if (nfail > g->fail_cap) return BVG_E_NOMEM;
+        out.resize(nfail);
+        if (nfail) HIPCHK(hipMemcpy(out.data(), g->d_fail + 1, nfail * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    auto timed = [&](const char* what, size_t nb, auto&& launch) -> int {
+        HIPCHK(hipEventRecord(g->ev0, g->stream));
+        launch();
+        HIPCHK(hipEventRecord(g->ev1, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+        kernel_ms += ms;
+        if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] %s: %zu blocks, %.3f ms\n", what, nb, ms);
+        return 0;
+    };
+
+    // ---- tier 0: every block, LDS sized for occupancy (the list pool holds one row of 64 lists + the window)
+    if (nblocks && !g->tun.force_slow) {
+        if (stream) {                                       // list ring: power of two
+            uint64_t want = (uint64_t)(avg * 72.0), cap = 2048;
+            while (cap * 2 <= want && cap < (wide ? 8192u : 16384u)) cap *= 2;
+            if (getenv("BVG_POOL")) cap = strtoull(getenv("BVG_POOL"), nullptr, 10);
+            a.lds_pool_elems = (uint32_t)cap; a.lds_scr_elems = 0;
+        } else {
+            uint64_t pool = ((uint64_t)(avg * 56.0) + 255) & ~255ull;   // ~a row of 64 lists (rows shrink when they do not fit)
+            pool = std::min<uint64_t>(std::max<uint64_t>(pool, 1024), wide ? 4096 : 8192);
+            if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
+            a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
+        }
+        r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
+                                              else launch_decode(a, nblocks, wide, materialise, false, g->stream); });
+        if (r) return r;
+        launches++;
+        r = fetch_failures(work); if (r) return r;
+    } else if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = lo + i; }
     slow_blocks = (uint32_t)work.size();
 
-    // slow path: same kernel over global-memory pools; grow the pool until every block fits
-    uint64_t pool_elems = 1ull << 20;
-    const size_t esz = wide ? 8 : 4;
-    while (!work.empty()) {
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        uint64_t scr_elems = pool_elems / 2;
-        uint64_t per_wg = (pool_elems + scr_elems) * esz;
-        uint64_t max_wgs = (free_b / 2) / per_wg;
-        if (max_wgs == 0) return BVG_E_NOMEM;
-        uint32_t batch = (uint32_t)std::min<uint64_t>({(uint64_t)work.size(), max_wgs, 1024});
-        void *gpool = nullptr, *gscr = nullptr; uint32_t* d_work = nullptr;
-        HIPCHK(hipMalloc(&gpool, (size_t)batch * pool_elems * esz));
-        HIPCHK(hipMalloc(&gscr, (size_t)batch * scr_elems * esz));
+    auto upload_work = [&]() -> int {
+        if (d_work) { (void)hipFree(d_work); d_work = nullptr; }
         HIPCHK(hipMalloc(&d_work, work.size() * sizeof(uint32_t)));
         HIPCHK(hipMemcpy(d_work, work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
-        a.gpool = gpool; a.gpool_elems = pool_elems; a.gscr = gscr; a.gscr_elems = scr_elems;
-        HIPCHK(hipEventRecord(g->ev0, g->stream));
-        for (size_t off = 0; off < work.size(); off += batch) {
-            uint32_t nb = (uint32_t)std::min<size_t>(batch, work.size() - off);
-            a.work_list = d_work + off;
-            launch_decode(a, nb, wide, materialise, true, g->stream);
-            launches++;
+        a.work_list = d_work;
+        return 0;
+    };
+    // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with most of a CU's LDS
+    if (!work.empty() && !g->tun.force_slow) {
+        r = upload_work(); if (r) return r;
+        a.lds_pool_elems = wide ? 6144 : 12288; a.lds_scr_elems = wide ? 768 : 1536; a.lds_stage_words = 1024;   // 58 KiB of dynamic LDS
+        const uint32_t nb = (uint32_t)work.size();
+        r = timed("tier1 (big LDS)", nb, [&] { launch_decode(a, nb, wide, materialise, false, g->stream); });
+        if (r) return r;
+        launches++;
+        r = fetch_failures(work); if (r) return r;
+    }
+    // ---- tier 2: global-memory pools (kept in the handle), grown until every remaining block fits
+    uint64_t pool_elems = 1ull << 20;
+    while (!work.empty()) {
+        uint64_t scr_elems = pool_elems / 2;
+        uint64_t per_wg = (pool_elems + scr_elems) * esz;
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(hipMemGetInfo(&free_b, &total_b));
+        uint32_t batch = (uint32_t)std::min<uint64_t>({(uint64_t)work.size(), std::max<uint64_t>(1, ((free_b + g->slow_ws_bytes) / 2) / per_wg), 1024});
+        if ((uint64_t)batch * per_wg > g->slow_ws_bytes) {
+            if (g->slow_ws) { (void)hipFree(g->slow_ws); g->slow_ws = nullptr; g->slow_ws_bytes = 0; }
+            if (hipMalloc(&g->slow_ws, (size_t)batch * per_wg) != hipSuccess) { if (d_work) (void)hipFree(d_work); return BVG_E_NOMEM; }
+            g->slow_ws_bytes = (uint64_t)batch * per_wg;
         }
-        HIPCHK(hipEventRecord(g->ev1, g->stream));
-        HIPCHK(hipStreamSynchronize(g->stream));
-        HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
-        kernel_ms += ms;
-        if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] slow launch: %zu blocks, pool %llu elems, %.3f ms\n", work.size(), (unsigned long long)pool_elems, ms);
-        uint32_t nfail = 0;
-        HIPCHK(hipMemcpy(&nfail, g->d_fail, sizeof(uint32_t), hipMemcpyDeviceToHost));
-        std::vector<uint32_t> next(nfail);
-        if (nfail) HIPCHK(hipMemcpy(next.data(), g->d_fail + 1, nfail * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        (void)hipFree(gpool); (void)hipFree(gscr); (void)hipFree(d_work);
-        work.swap(next);
+        r = upload_work(); if (r) return r;
+        a.gpool = g->slow_ws; a.gpool_elems = pool_elems;
+        a.gscr = (char*)g->slow_ws + (size_t)batch * pool_elems * esz; a.gscr_elems = scr_elems;
+        a.lds_stage_words = 1024;
+        const size_t nwork = work.size();
+        r = timed("tier2 (global)", nwork, [&] {
+            for (size_t off = 0; off < nwork; off += batch) {
+                uint32_t nb = (uint32_t)std::min<size_t>(batch, nwork - off);
+                a.work_list = d_work + off;
+                launch_decode(a, nb, wide, materialise, true, g->stream);
+                launches++;
+            }
+        });
+        if (r) return r;
+        r = fetch_failures(work); if (r) return r;
         if (!work.empty()) {
-            if (pool_elems >= (1ull << 34)) return BVG_E_NOMEM;
+            if (pool_elems >= (1ull << 34)) { if (d_work) (void)hipFree(d_work); return BVG_E_NOMEM; }
             pool_elems *= 8;
         }
     }
+    if (d_work) (void)hipFree(d_work);
 
     unsigned long long acc[4];
     HIPCHK(hipMemcpy(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost));
@@ -504,6 +541,7 @@ void bvg_close(bvg_graph* g) {
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->d_acc) (void)hipFree(g->d_acc);
     if (g->d_fail) (void)hipFree(g->d_fail);
+    if (g->slow_ws) (void)hipFree(g->slow_ws);
     release_shared(g->sh);
     delete g;
 }

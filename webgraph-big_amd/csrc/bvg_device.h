@@ -33,11 +33,15 @@ struct BitCursor {
     const uint8_t* base;
     uint64_t pos;          // absolute bit position
     uint64_t limit_byte;
-    // Optional LDS window over the stream: win[i] = big-endian dword i of the staged bytes, the first
-    // staged bit being absolute bit win_bit0.  Positions outside it fall back to global memory.
+    // Optional LDS window over the stream: win[i & win_mask] = big-endian dword i of the staged bytes,
+    // dword 0 starting at absolute bit win_bit0; bits [win_lo, win_hi) (relative to win_bit0) are valid.
+    // A linear window has win_mask = ~0u, win_lo = 0; a ring keeps the last (win_mask+1) dwords.
+    // Positions outside the window fall back to global memory.
     const uint32_t* win = nullptr;
     uint64_t win_bit0 = 0;
-    uint32_t win_bits = 0;
+    uint32_t win_hi = 0;
+    uint32_t win_lo = 0;
+    uint32_t win_mask = 0xFFFFFFFFu;
 
     __device__ __forceinline__ uint64_t peek_global() const {
         uint64_t byte = pos >> 3;
@@ -52,9 +56,9 @@ struct BitCursor {
     }
     __device__ __forceinline__ uint64_t peek() const {
         const uint64_t rel = pos - win_bit0;
-        if (rel + 96 <= (uint64_t)win_bits) {                 // (wraps to huge when pos < win_bit0)
+        if (rel >= (uint64_t)win_lo && rel + 96 <= (uint64_t)win_hi) {   // (wraps to huge when pos < win_bit0)
             const uint32_t wi = (uint32_t)rel >> 5, sh = (uint32_t)rel & 31u;
-            const uint32_t a = win[wi], b = win[wi + 1], c = win[wi + 2];
+            const uint32_t a = win[wi & win_mask], b = win[(wi + 1) & win_mask], c = win[(wi + 2) & win_mask];
             const uint64_t ab = ((uint64_t)a << 32) | b;
             return sh ? (ab << sh) | (uint64_t)(c >> (32u - sh)) : ab;
         }

@@ -36,9 +36,13 @@ struct DecodeArgs {
     void* gpool; uint64_t gpool_elems; void* gscr; uint64_t gscr_elems;
     // fast path: LDS pool / scratch sizes in elements (dynamic shared memory)
     uint32_t lds_pool_elems, lds_scr_elems;
+    uint32_t lds_stage_words;           // row-static kernel: LDS window over the stream, in dwords (multiple of 4)
+    uint32_t grab_threshold;            // stream kernel: idle lanes that trigger a batched grab
 };
 
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
+// the streaming data-flow kernel (bvg_stream.hip): fast path; lds_pool_elems must be a power of two
+void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 
 // thread per node: outdegree (BVG:821-842)
 void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,

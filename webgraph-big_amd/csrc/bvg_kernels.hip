@@ -30,7 +30,6 @@ namespace {
 
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 
-constexpr uint32_t kStageBytes = 4096;     // LDS window over the .graph stream (one default block)
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
@@ -59,7 +58,6 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     typedef Rd<GEN> R;
     constexpr uint32_t RM = kRing - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // fast path: pool then scratch
-    __shared__ uint32_t stage[kStageBytes / 4];
     typedef typename std::conditional<SLOW, uint64_t, uint32_t>::type idx_t;
     __shared__ idx_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
@@ -79,6 +77,9 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     T* const scr = SLOW ? reinterpret_cast<T*>(a.gscr) + (uint64_t)blockIdx.x * a.gscr_elems : reinterpret_cast<T*>(dyn_lds) + a.lds_pool_elems;
     const uint64_t CAP = SLOW ? a.gpool_elems : a.lds_pool_elems;
     const uint64_t SCR = SLOW ? a.gscr_elems : a.lds_scr_elems;
+    // the stream window lives behind pool + scratch in the dynamic LDS block (slow path: at its start)
+    uint32_t* const stage = reinterpret_cast<uint32_t*>(dyn_lds + (SLOW ? 0 : (size_t)(a.lds_pool_elems + a.lds_scr_elems) * sizeof(T)));
+    const uint32_t stage_bytes = a.lds_stage_words * 4u;
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
     __syncthreads();
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 __syncthreads();
                 const uint64_t b0 = (row_lo >> 3) & ~15ull;
                 uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
-                if (nb > kStageBytes) nb = kStageBytes;
+                if (nb > stage_bytes) nb = stage_bytes;
                 for (uint32_t c = lane; c < (uint32_t)(nb >> 4); c += 64) {
                     const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
                     uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 __syncthreads();
             }
         }
-        BitCursor cur{a.graph, off_x, a.limit_byte, stage, stg_bit0, stg_bits};
+        BitCursor cur{a.graph, off_x, a.limit_byte, stage, stg_bit0, stg_bits, 0u, 0xFFFFFFFFu};
         uint32_t d = 0;
         if (needed) d = (uint32_t)R::outdegree(cur, a.cod, rec_end);          // readOutdegree, BVG:654-660
         // how many leading lanes fit in the pool?
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 }
                 if (!(bc & 1)) copied += (int64_t)nd_d[(uint64_t)(x - ref) & RM] - tot;   // BVG:1030
                 extra = (int64_t)d - copied;
-                if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
+                if (extra < 0 || copied < 0) { err |= ERR_MALFORMED; extra = 0; }      // never let a tail start before the list
             }
             if (extra > 0 && a.min_interval != 0) {                          // BVG:1037-1060 (always gamma)
                 uint64_t ni = cur.read_gamma(rec_end);
@@ -459,7 +460,7 @@ void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materi
     dim3 grid(nblocks), block(64);
     const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
-    const size_t dyn = slow ? 0 : (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4);
+    const size_t dyn = (slow ? 0 : (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4)) + (size_t)a.lds_stage_words * 4;
 #define BVG_LAUNCH2(T, M, S) do { if (gen) hipLaunchKernelGGL((decode_kernel<T, M, S, true>), grid, block, dyn, s, a); \
                                   else hipLaunchKernelGGL((decode_kernel<T, M, S, false>), grid, block, dyn, s, a); } while (0)
 #define BVG_LAUNCH(T, M, S) BVG_LAUNCH2(T, M, S)
