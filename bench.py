@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream", action="store_true", help="use the experimental streaming data-flow kernel as tier 0 (A/B)")
     ap.add_argument("--grab-threshold", type=int, default=0)
+    ap.add_argument("--legacy", action="store_true", help="generic (BitCursor) row kernel as tier 0/1 (A/B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,8 +82,8 @@ def main():
     torch.cuda.synchronize()
     upload_s = time.time() - t0
     g = base.tile(copies) if copies > 1 else base
-    if args.block_bits or args.stream or args.grab_threshold:
-        g.set_tuning(block_bits=args.block_bits, stream=args.stream, grab_threshold=args.grab_threshold)
+    if args.block_bits or args.stream or args.grab_threshold or args.legacy:
+        g.set_tuning(block_bits=args.block_bits, stream=args.stream, grab_threshold=args.grab_threshold, legacy=args.legacy)
     n_local = g.num_nodes()
     g.set_node_base(rank * n_local)                                     # shard `rank` of the N-times larger graph
     arcs_local = st.stats["arcs"] * copies

@@ -64,7 +64,7 @@ def test_block_size_does_not_change_results(W, cnr_csr, oracle, block_bits):
 
 
 def test_wide_and_slow_paths_are_bit_exact(W, cnr_csr):
-    for kw in ({"force_wide": True}, {"force_slow": True}, {"force_wide": True, "force_slow": True}, {"stream": True}, {"stream": True, "force_wide": True}):
+    for kw in ({"force_wide": True}, {"force_slow": True}, {"force_wide": True, "force_slow": True}, {"stream": True}, {"stream": True, "force_wide": True}, {"legacy": True}):
         g = W.BVGraph.load(CNR)
         g.set_tuning(**kw)
         deg, succ = g.decode_range(0, 60000)

@@ -351,9 +351,9 @@ class BVGraph:
     def set_node_base(self, base):
         _check(lib().bvg_set_node_base(self._h, base), "set_node_base")
 
-    def set_tuning(self, block_bits=0, force_wide=False, force_slow=False, stream=False, grab_threshold=0):
+    def set_tuning(self, block_bits=0, force_wide=False, force_slow=False, stream=False, grab_threshold=0, legacy=False):
         """stream=True selects the experimental streaming data-flow kernel (bvg_stream.hip) as tier 0."""
-        t = Tuning(block_bits, int(force_wide), int(force_slow), (2 if stream else 0) | (int(grab_threshold) << 8))
+        t = Tuning(block_bits, int(force_wide), int(force_slow), (2 if stream else (1 if legacy else 0)) | (int(grab_threshold) << 8))
         _check(lib().bvg_set_tuning(self._h, C.byref(t)), "set_tuning")
 
     def offsets(self):

@@ -139,7 +139,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
     HIPCHK(hipEventCreate(&g->ev1));
     HIPCHK(hipMalloc(&g->d_acc, 4 * sizeof(unsigned long long)));
     g->fail_cap = 1u << 16;
-    HIPCHK(hipMalloc(&g->d_fail, (g->fail_cap + 1) * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     *out = g;
     return 0;
 }
@@ -235,7 +235,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (nblocks > g->fail_cap) {                            // every block may fail over to the slow path
         (void)hipFree(g->d_fail); g->d_fail = nullptr;
         g->fail_cap = nblocks;
-        HIPCHK(hipMalloc(&g->d_fail, ((size_t)g->fail_cap + 1) * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     }
     HIPCHK(hipMemsetAsync(g->d_acc, 0, 4 * sizeof(unsigned long long), g->stream));
     HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
@@ -246,8 +246,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.blk_first = pl.d_first; a.blk_halo = pl.d_halo; a.blk_mask = pl.d_mask; a.work_list = nullptr; a.blk_lo = lo;
     a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
     a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
-    a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap;
+    a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
+    a.dbg = getenv("BVG_DBG") ? (uint32_t)strtoul(getenv("BVG_DBG"), nullptr, 10) : 0;
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
+    const bool legacy = (g->tun.reserved & 0xFF) == 1;     // A/B switch: the generic row kernel (BitCursor) in LDS as tier 0/1
     a.grab_threshold = (g->tun.reserved >> 8) ? (g->tun.reserved >> 8) : 40;
     const size_t esz = wide ? 8 : 4;
     const double avg = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
@@ -296,7 +298,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
         }
         r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
-                                              else launch_decode(a, nblocks, wide, materialise, false, g->stream); });
+                                              else if (legacy) launch_decode(a, nblocks, wide, materialise, false, g->stream);
+                                              else launch_rows_decode(a, nblocks, wide, materialise, g->stream); });
         if (r) return r;
         launches++;
         r = fetch_failures(work); if (r) return r;
@@ -311,15 +314,33 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         a.work_list = d_work;
         return 0;
     };
-    // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with most of a CU's LDS
+    // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with a pool sized to
+    //      what each block reported it needs (size classes keep as many waves resident as possible)
     if (!work.empty() && !g->tun.force_slow) {
-        r = upload_work(); if (r) return r;
-        a.lds_pool_elems = wide ? 6144 : 12288; a.lds_scr_elems = wide ? 768 : 1536; a.lds_stage_words = 1024;   // 58 KiB of dynamic LDS
-        const uint32_t nb = (uint32_t)work.size();
-        r = timed("tier1 (big LDS)", nb, [&] { launch_decode(a, nb, wide, materialise, false, g->stream); });
-        if (r) return r;
-        launches++;
-        r = fetch_failures(work); if (r) return r;
+        std::vector<uint32_t> need(work.size());
+        HIPCHK(hipMemcpy(need.data(), g->d_fail + 1 + g->fail_cap, work.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const uint32_t max_pool = wide ? 6144 : 12288;
+        const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
+        std::vector<uint32_t> bins[4], rest;
+        for (size_t i = 0; i < work.size(); i++) {
+            int c = 3;
+            if (!stream && !legacy && need[i] != 0xFFFFFFFFu) { c = 0; while (c < 3 && classes[c] < need[i]) c++; if (classes[c] < need[i]) c = -1; }
+            if (c < 0) rest.push_back(work[i]); else bins[c].push_back(work[i]);
+        }
+        for (int c = 0; c < 4; c++) {
+            if (bins[c].empty()) continue;
+            work.swap(bins[c]);
+            r = upload_work(); if (r) return r;
+            a.lds_pool_elems = classes[c]; a.lds_scr_elems = std::max<uint32_t>(512, classes[c] / 8); a.lds_stage_words = 1024;
+            const uint32_t nb = (uint32_t)work.size();
+            r = timed("tier1 (big LDS)", nb, [&] { if (legacy) launch_decode(a, nb, wide, materialise, false, g->stream); else launch_rows_decode(a, nb, wide, materialise, g->stream); });
+            if (r) return r;
+            launches++;
+            std::vector<uint32_t> again;
+            r = fetch_failures(again); if (r) return r;
+            rest.insert(rest.end(), again.begin(), again.end());
+        }
+        work.swap(rest);
     }
     // ---- tier 2: global-memory pools (kept in the handle), grown until every remaining block fits
     uint64_t pool_elems = 1ull << 20;

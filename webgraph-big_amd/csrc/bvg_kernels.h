@@ -32,15 +32,19 @@ struct DecodeArgs {
     int64_t* succ; int32_t* outdeg;
     // slow path hand-off
     uint32_t* fail_list; uint32_t* fail_count; uint32_t fail_cap;
+    uint32_t* fail_need;                // per failed block: list-pool elements it would need (0xFFFFFFFF = unknown / other cause)
     // slow-path pools (global memory), per workgroup
     void* gpool; uint64_t gpool_elems; void* gscr; uint64_t gscr_elems;
     // fast path: LDS pool / scratch sizes in elements (dynamic shared memory)
     uint32_t lds_pool_elems, lds_scr_elems;
     uint32_t lds_stage_words;           // row-static kernel: LDS window over the stream, in dwords (multiple of 4)
     uint32_t grab_threshold;            // stream kernel: idle lanes that trigger a batched grab
+    uint32_t dbg;                       // timing experiments only (BVG_DBG): 1 skip emission, 2 skip residual decode, 4 skip parse
 };
 
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
+// the lean LDS-resident row kernel (bvg_rows.hip): tiers 0 and 1
+void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 // the streaming data-flow kernel (bvg_stream.hip): fast path; lds_pool_elems must be a power of two
 void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 

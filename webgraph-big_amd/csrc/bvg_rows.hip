@@ -1,0 +1,376 @@
+// bvg_rows.hip — the LDS-resident row kernel (tiers 0 and 1 of the decode).
+//
+// One wavefront (a 64-thread workgroup) owns one node block and walks it in ROWS of up to 64
+// consecutive nodes, one node per lane.  Everything the row touches lives in LDS:
+//   * a linear window over the .graph stream (coalesced 16 B/lane loads, byte-swapped once), read
+//     with the lean decoders of bvg_lds_codes.h (two/three ds_read_b32 + funnel shift per code);
+//   * the list pool: the successor lists of the row and of the <= W nodes before it (compacted when
+//     full, so a block may be arbitrarily long at a bounded footprint);
+//   * a scratch area with the row's copy blocks and intervals.
+// Phase 1 (parse): every lane decodes its own record — outdegree gamma, reference unary, copy blocks
+// gamma, intervals gamma, residual gaps zeta_k turned into absolute values at the tail of the
+// node's own list (BVGraph.java:1003-1064).  Phase 2 (emit): a lock-step data-flow loop; per
+// iteration each lane emits one successor by the three-way merge {masked copy of the referenced
+// list, intervals, residuals} of BVGraph.java:1062-1090; a lane whose referenced list belongs to a
+// lower lane of the same row waits on that lane's `produced` counter, so reference chains pipeline.
+// The LDS footprint is kept as small as the graph allows because resident waves per CU — not HBM
+// bandwidth — bound this kernel (profiles/README.md).
+//
+// Whatever does not fit (a list larger than the pool, a record larger than the window, a code
+// longer than 64 bits) makes the block fail over to the next tier (bigger LDS, then the generic
+// global-memory kernel in bvg_kernels.hip).
+#include "bvg_kernels.h"
+#include "bvg_lds_codes.h"
+
+namespace bvg {
+
+namespace {
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t LIN = 0xFFFFFFFFu;          // linear window: no index mask
+constexpr uint32_t RM = kRing - 1;
+
+template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = __shfl_up(v, o, 64);
+        if ((int)lane_id() >= o) v += t;
+    }
+    return v;
+}
+
+template <typename T, bool MAT, bool GEN>
+__global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
+    __shared__ uint32_t nd_base[kRing];
+    __shared__ uint32_t nd_d[kRing];
+    __shared__ uint32_t produced[64];
+    __shared__ uint32_t scr_used;
+
+    const unsigned lane = threadIdx.x;
+    const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
+    const int64_t s = (int64_t)a.blk_first[bid], e = (int64_t)a.blk_first[bid + 1];
+    if (e <= a.from || s >= a.to || s >= e) return;
+    const uint32_t halo = a.blk_halo[bid];
+    const uint64_t hmask = a.blk_mask[bid];
+    const uint32_t W = (uint32_t)a.window;
+    const int64_t hs = s - (int64_t)halo;
+    const int64_t rep_lo = s > a.from ? s : a.from, rep_hi = e < a.to ? e : a.to;
+
+    T* const pool = reinterpret_cast<T*>(dyn_lds);
+    T* const scr = pool + a.lds_pool_elems;
+    const uint32_t* const stage = reinterpret_cast<const uint32_t*>(scr + a.lds_scr_elems);
+    uint32_t* const stage_w = const_cast<uint32_t*>(stage);
+    const uint32_t CAP = a.lds_pool_elems, SCR = a.lds_scr_elems;
+    const uint32_t stage_bits = a.lds_stage_words * 32u;
+    const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
+    const bool zfast = !GEN && zk >= 2;
+
+    for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
+    __syncthreads();
+
+    uint32_t pool_used = 0;
+    uint64_t stg_bit0 = 0; uint32_t stg_bits = 0;             // staged window (wave-uniform)
+    uint64_t blk_arcs = 0, blk_chk = 0, blk_nodes = 0;
+    unsigned err = 0;
+    bool failed = false;
+    uint32_t fail_need = 0xFFFFFFFFu;                        // pool elements that would have been enough (when known)
+
+    int64_t r0 = hs;
+    // offsets of the first row (later rows are prefetched while the previous row is decoded)
+    uint64_t off_x = 0, rec_end = 0;
+    if (r0 + lane < e) { off_x = a.offsets[r0 + lane]; rec_end = a.offsets[r0 + lane + 1]; }
+
+    while (r0 < e) {
+        // ------------------------------------------------------------------ row set-up
+        const int64_t x = r0 + lane;
+        const bool in_range = x < e;
+        const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
+        const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
+        const uint32_t left = (uint32_t)(e - r0 > 64 ? 64 : e - r0);
+        {   // (re)stage the window when this row's records are not covered by it
+            const uint64_t row_lo = __shfl(off_x, 0, 64);
+            const uint64_t row_hi = __shfl(rec_end, (int)left - 1, 64);
+            if (!(row_lo >= stg_bit0 && row_hi + 96 <= stg_bit0 + stg_bits)) {
+                __syncthreads();
+                const uint64_t b0 = (row_lo >> 3) & ~15ull;
+                uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
+                if (nb > (stage_bits >> 3)) nb = stage_bits >> 3;
+                for (uint32_t c = lane; c < (uint32_t)(nb >> 4); c += 64) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
+                    uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
+                    *reinterpret_cast<uint4*>(&stage_w[c << 2]) = w;
+                }
+                stg_bit0 = b0 << 3; stg_bits = (uint32_t)(nb << 3);
+                __syncthreads();
+            }
+        }
+        // rows are cut where the records stop fitting the window (the next row restages from there)
+        const bool inwin = in_range && rec_end + 96 <= stg_bit0 + stg_bits && off_x >= stg_bit0;
+        uint32_t kwin = (uint32_t)__popcll(ballot(inwin) & (left == 64 ? ~0ull : ((1ull << left) - 1)));
+        {   // contiguous prefix only
+            const uint64_t m = ballot(inwin);
+            kwin = m == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~m) - 1u;
+            if (kwin > left) kwin = left;
+        }
+        if (kwin == 0) { failed = true; break; }                              // a single record larger than the window
+        uint32_t rel = (uint32_t)(off_x - stg_bit0);                          // bit cursor relative to the window
+        const uint32_t pend = (uint32_t)(rec_end - stg_bit0);
+        bool bad = false;
+        uint64_t v;
+        uint32_t d = 0;
+        if (needed && lane < kwin) {                                          // readOutdegree, BVG:654-660
+            const uint64_t w = win64<LIN>(stage, rel);
+            const uint32_t l = GEN ? decode_generic_w(w, a.cod.outdegree, 0, &v) : gamma64(w, v);
+            bad |= l == 0 || v > 0x7FFFFFFFull; rel += l; d = bad ? 0u : (uint32_t)v;
+        }
+        // how many leading lanes fit in the pool?
+        const uint32_t dclamp = d > CAP ? CAP + 1 : d;
+        const uint32_t incl = wave_incl_scan32(dclamp);
+        uint32_t avail = CAP - pool_used;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (total > avail && pool_used > 0) {
+            // compact: keep only the lists of the last W nodes, moved to the front of the pool
+            uint32_t my_d = 0, my_base = 0; const int64_t y = r0 - (int64_t)W + (int64_t)lane;
+            const bool livelane = lane < W && y >= hs;
+            if (livelane) { my_d = nd_d[(uint32_t)y & RM]; my_base = nd_base[(uint32_t)y & RM]; }
+            const uint32_t nincl = wave_incl_scan32(my_d);
+            const uint32_t nbase = nincl - my_d;
+            for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
+                const uint32_t src = __shfl(my_base, (int)jn, 64), dst = __shfl(nbase, (int)jn, 64), len = __shfl(my_d, (int)jn, 64);
+                if (src != dst)
+                    for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
+            }
+            if (livelane) nd_base[(uint32_t)y & RM] = nbase;
+            pool_used = __shfl(nincl, 63, 64);
+            avail = CAP - pool_used;
+            __syncthreads();
+        }
+        uint32_t k = kwin;
+        if (total > avail) { const uint32_t kf = (uint32_t)__popcll(ballot(incl <= avail)); k = kf < k ? kf : k; }
+        if (k == 0) {                                                         // first node alone overflows the pool
+            failed = true;
+            if (kwin) { const uint32_t d0 = __shfl(d, 0, 64); fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFFFu : d0 + pool_used + (d0 >> 2) + 64; }
+            break;
+        }
+        const bool act = needed && lane < k;
+        const uint32_t base = pool_used + (incl - dclamp);
+        if (act) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
+        pool_used += __shfl(incl, (int)k - 1, 64);
+        if (lane == 0) scr_used = 0;
+        produced[lane] = act ? 0u : kInf;
+        // prefetch the next row's offsets (their latency hides behind this row's decode)
+        uint64_t nxt_off = 0, nxt_end = 0;
+        {
+            const int64_t nx = r0 + k + lane;
+            if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
+        }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase 1: parse own record
+        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
+        bool overflow = false;
+        if (act && d > 0 && !(a.dbg & 4)) {
+            if (W > 0) {                                                      // BVG:1015; readReference, BVG:692-703
+                const uint64_t w = win64<LIN>(stage, rel);
+                uint32_t l;
+                if (GEN) l = decode_generic_w(w, a.cod.reference, 0, &v);
+                else { const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u; v = lz; l = lz < 64 ? lz + 1 : 0; }
+                bad |= l == 0; rel += l;
+                if (v > W || (int64_t)v > x) { err |= ERR_REF_RANGE; v = 0; }
+                ref = (uint32_t)v;
+            }
+            int64_t extra = d;
+            if (ref > 0) {                                                    // BVG:1020-1032
+                const uint64_t w = win64<LIN>(stage, rel);
+                const uint32_t l = GEN ? decode_generic_w(w, a.cod.block_count, 0, &v) : gamma64(w, v);
+                bad |= l == 0 || v > pend - rel + 1; rel += l; bc = bad ? 0u : (uint32_t)v;
+                sb = atomicAdd(&scr_used, bc);
+                if (sb + bc > SCR) { overflow = true; bc = 0; }
+                int64_t copied = 0, tot = 0;
+                for (uint32_t i = 0; i < bc; i++) {
+                    const uint64_t wb = win64<LIN>(stage, rel);
+                    const uint32_t lb = GEN ? decode_generic_w(wb, a.cod.block, 0, &v) : gamma64(wb, v);
+                    if (lb == 0 || rel > pend) { bad = true; bc = i; break; }
+                    rel += lb;
+                    const uint32_t b = (uint32_t)v + (i ? 1u : 0u);
+                    scr[sb + i] = (T)b;
+                    tot += b;
+                    if (!(i & 1)) copied += b;
+                }
+                if (!(bc & 1)) copied += (int64_t)nd_d[(uint32_t)(x - ref) & RM] - tot;      // BVG:1030
+                extra = (int64_t)d - copied;
+                if (extra < 0 || copied < 0) { err |= ERR_MALFORMED; extra = 0; }       // never let a tail start before the list
+            }
+            if (extra > 0 && minint != 0) {                                   // BVG:1037-1060 (always gamma)
+                uint32_t l = gamma64(win64<LIN>(stage, rel), v);
+                bad |= l == 0 || v > (pend - rel) / 2 + 1; rel += l; ic = bad ? 0u : (uint32_t)v;
+                ib = atomicAdd(&scr_used, 2 * ic);
+                if (ib + 2 * ic > SCR) { overflow = true; ic = 0; }
+                int64_t prev = 0;
+                for (uint32_t i = 0; i < ic; i++) {
+                    uint64_t v1, v2;
+                    const uint32_t l1 = gamma64(win64<LIN>(stage, rel), v1);
+                    const uint32_t l2 = gamma64(win64<LIN>(stage, rel + l1), v2);
+                    if (l1 == 0 || l2 == 0 || rel > pend) { bad = true; ic = i; break; }
+                    rel += l1 + l2;
+                    const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
+                    const int64_t len = (int64_t)v2 + minint;
+                    prev = leftv + len;
+                    extra -= len;
+                    scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
+                }
+                if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
+            }
+            nres = (uint32_t)extra;
+            if (nres > 0 && !overflow && !bad && !(a.dbg & 2)) {                              // ResidualLongIterator, BVG:902-935
+                T* const tail = pool + base + d - nres;
+                T r = (T)x;
+                for (uint32_t t = 0; t < nres; t++) {
+                    uint64_t val = 0; uint32_t len = 0;
+                    if (zfast) {                                              // zeta_k from a 32-bit window
+                        const uint32_t w = win32<LIN>(stage, rel);
+                        const uint32_t z = w ? (uint32_t)__builtin_clz(w) : 32u;
+                        const uint32_t nbz = z * zk + zk - 1, zt = z + 1 + nbz;
+                        if (zt < 32) {
+                            const uint32_t tt = (w << (z + 1)) >> (32u - nbz);
+                            const uint32_t leftv = 1u << (z * zk);
+                            if (tt < leftv) { val = tt + leftv - 1u; len = zt; }
+                            else { val = ((tt << 1) | ((w >> (31u - zt)) & 1u)) - 1u; len = zt + 1; }
+                        }
+                    }
+                    if (len == 0) {                                           // long code / other coding: 64-bit window
+                        const uint64_t w = win64<LIN>(stage, rel);
+                        len = GEN ? decode_generic_w(w, a.cod.residual, zk, &val) : zeta64(w, zk, val);
+                        if (len == 0) { bad = true; break; }
+                    }
+                    rel += len;
+                    r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
+                    tail[t] = r;
+                    if (rel > pend) { err |= ERR_OVERRUN; break; }
+                }
+            }
+            if (rel != pend && !overflow && !bad && !a.dbg) err |= ERR_MALFORMED;      // SURVEY A.6 self-check
+        } else if (act && rel != pend && !bad) err |= ERR_MALFORMED;
+        if (ballot(overflow || bad)) { failed = true; break; }
+        __syncthreads();
+
+        // ------------------------------------------------------------------ phase 2: data-flow emission
+        const bool rep = act && x >= rep_lo && x < rep_hi;
+        uint32_t k0 = 0, k1 = 0;
+        if (rep && !MAT) { const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k0 = (uint32_t)kx; k1 = (uint32_t)(kx >> 32) | 1u; }
+        T* const out = pool + base;
+        const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; uint32_t rlane = lane; bool samerow = false;
+        if (act && ref > 0) {
+            const int64_t y = x - ref;
+            rl = pool + nd_base[(uint32_t)y & RM]; rlen = nd_d[(uint32_t)y & RM];
+            if (y >= r0) { rlane = lane - ref; samerow = true; }
+            if (bc == 0) keep = kInf;                                         // MaskedLongIterator.java:73-78
+            else {
+                keep = (uint32_t)scr[sb]; bi = 1;
+                if (keep == 0) {
+                    if (bi >= bc) rpos = rlen;
+                    else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
+                }
+            }
+        }
+        T ivcur = 0; uint32_t ivrem = 0, ivi = 0;
+        if (ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }
+        uint32_t rsi = 0;
+        T rhead = nres ? out[d - nres] : sentinel<T>();
+        uint32_t j = 0;
+        uint64_t chk = 0;
+        volatile uint32_t* vprod = produced;
+        for (;;) {
+            const bool todo = act && j < d && !(a.dbg & 1);
+            if (!ballot(todo)) break;
+            const bool cneed = todo && rpos < rlen;
+            // both loads are issued together; the copy head is only used when the producer is far enough
+            const uint32_t pr = vprod[rlane];
+            const T cval = rl[cneed ? rpos : 0];
+            const bool cready = !cneed || !samerow || pr > rpos;
+            if (todo && cready) {
+                const T c = cneed ? cval : sentinel<T>();
+                const T iv = ivrem ? ivcur : sentinel<T>();
+                T m = c < iv ? c : iv; m = m < rhead ? m : rhead;             // MergedLongIterator.java:63-92, three-way
+                out[j] = m;
+                j++;
+                vprod[lane] = j;
+                if (!MAT && rep) {
+                    const uint64_t y64 = m == sentinel<T>() ? ~0ull : (uint64_t)m + a.node_base;
+                    chk += mix_keyed(k0, k1, y64);
+                }
+                if (cneed && c == m) {                                        // MaskedLongIterator.java:81-100
+                    rpos++;
+                    if (--keep == 0) {
+                        if (bi >= bc) rpos = rlen;
+                        else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
+                    }
+                }
+                if (ivrem && iv == m) {                                       // LongIntervalSequenceIterator.java:71-78
+                    ivcur++;
+                    if (--ivrem == 0 && ivi < ic) { ivcur = scr[ib + 2 * ivi]; ivrem = (uint32_t)scr[ib + 2 * ivi + 1]; ivi++; }
+                }
+                if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? out[d - nres + rsi] : sentinel<T>(); }
+            }
+        }
+        if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }
+
+        // ------------------------------------------------------------------ materialise: coalesced copy-out
+        if (MAT) {
+            __syncthreads();
+            const uint64_t repmask = ballot(rep);
+            if (repmask) {
+                const int la = __ffsll((unsigned long long)repmask) - 1;
+                const int lb = 63 - __clzll(repmask);
+                const uint32_t seg0 = __shfl(base, la, 64);
+                const uint32_t seg1 = __shfl(base + d, lb, 64);
+                const uint64_t dst0 = a.cum[(r0 + la) - a.from];
+                for (uint32_t t = lane; t < seg1 - seg0; t += 64) {
+                    const T vv = pool[seg0 + t];
+                    a.succ[dst0 + t] = vv == sentinel<T>() ? -1ll : (int64_t)((uint64_t)vv + a.node_base);
+                }
+                if (rep && a.outdeg) a.outdeg[x - a.from] = (int32_t)d;
+            }
+        }
+        __syncthreads();
+        // next row: lanes shift by k; reuse the prefetched offsets
+        r0 += k;
+        off_x = nxt_off; rec_end = nxt_end;
+    }
+
+    err = wave_or32(err);
+    if (failed) {
+        if (lane == 0) {
+            uint32_t slot = atomicAdd(a.fail_count, 1u);
+            if (slot < a.fail_cap) { a.fail_list[slot] = bid; if (a.fail_need) a.fail_need[slot] = fail_need; }
+        }
+        return;
+    }
+    blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
+    if (lane == 0) {
+        atomicAdd(&a.acc[0], (unsigned long long)blk_arcs);
+        atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
+        atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
+        if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+    }
+}
+
+}  // namespace
+
+void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s) {
+    if (nblocks == 0) return;
+    dim3 grid(nblocks), block(64);
+    const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
+                       a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
+    const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (size_t)a.lds_stage_words * 4;
+#define BVG_RL(T, M) do { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true>), grid, block, dyn, s, a); \
+                          else hipLaunchKernelGGL((rows_kernel<T, M, false>), grid, block, dyn, s, a); } while (0)
+    if (!wide) { if (!materialise) BVG_RL(uint32_t, false); else BVG_RL(uint32_t, true); }
+    else { if (!materialise) BVG_RL(uint64_t, false); else BVG_RL(uint64_t, true); }
+#undef BVG_RL
+}
+
+}  // namespace bvg
