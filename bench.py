@@ -142,7 +142,7 @@ def main():
                        "bits_per_link": 8.0 * r["graph_bytes"] / arcs_local, "tiles": copies, "base_nodes": args.base_nodes,
                        "sharding": "node ranges, %d shard(s); RCCL all-reduce of {arcs,chk} only" % args.gpus},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "bvg::decode_kernel<u32,scan>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "bvg::rows_kernel<u32,scan> (tiers 0/1) + decode_kernel<slow> (tier 2): sum of one scan's launches", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": r["graph_bytes"], "index_bytes_per_launch": r["index_bytes"]},
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
             "host": {"generate_s": gen_s, "upload_s": upload_s, "upload_GBps": base_bytes / max(upload_s, 1e-9) / 1e9},

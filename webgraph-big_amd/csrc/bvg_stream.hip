@@ -45,7 +45,7 @@ constexpr uint32_t kRingBits = kStreamWords * 32;
 constexpr uint32_t kBlkRing = 512;            // block ring entries
 constexpr uint32_t BRM = kBlkRing - 1;
 constexpr uint32_t kInf = 0xFFFFFFFFu;
-constexpr unsigned kGrabThreshold = 12;       // idle lanes that trigger a batched grab
+
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
     return v;
 }
 
-constexpr uint32_t kRingMask = SWM;
+
 __device__ __forceinline__ uint32_t win32(const uint32_t* r, uint32_t rel) { return bvg::win32<SWM>(r, rel); }
 __device__ __forceinline__ uint64_t win64(const uint32_t* r, uint32_t rel) { return bvg::win64<SWM>(r, rel); }
 __device__ __forceinline__ uint32_t decode_generic(const uint32_t* r, uint32_t rel, int coding, uint32_t k, uint64_t* out) { return decode_generic_w(bvg::win64<SWM>(r, rel), coding, k, out); }
