@@ -117,6 +117,11 @@ int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out);
 int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Same, successor / outdegree buffers in device memory (stay in HBM for a downstream kernel). */
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ);
+/* successors(x) for a whole frontier at once (BVG:860-867 per element; the access pattern of
+ * algo/ParallelBreadthFirstVisit.java and algo/HyperBall.java:774-822): nodes[count] in any order, repeats
+ * allowed; outdeg[count] and the successor lists concatenated in request order.  Each request is
+ * decoded together with the few earlier nodes its reference chain reaches (the recursion of BVG:1084). */
+int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum). */
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of

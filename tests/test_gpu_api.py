@@ -184,3 +184,56 @@ def test_wide_ids_beyond_32_bits(W, tools, oracle):
     assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]
     g.set_tuning(force_wide=True)
     assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]
+
+
+def test_full_size_properties_on_a_tiled_graph(W, tools, oracle):
+    """Size-independent properties at bench scale (a ~0.5 GiB tiled stream, hundreds of millions of arcs):
+    (1) the checksum of K tiles equals the sum of K base scans with shifted node bases (translation
+    invariance + additivity), (2) arcs = K x base arcs, (3) node-range shards add up to the whole,
+    (4) sampled ranges deep inside the tiled graph materialise bit-exactly against the oracle."""
+    n = 1 << 17
+    st = tools.synth_store(n, seed=13, threads=8)
+    base = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    K = max(2, (512 << 20) // max(len(st.graph), 1))
+    big = base.tile(K)
+    assert big.num_nodes() == K * n
+    whole = big.scan()
+    assert whole["arcs"] == K * st.stats["arcs"] and whole["nodes"] == K * n
+    want = 0
+    for j in (0, 1, K // 2, K - 1):
+        base.set_node_base(j * n)
+        r = base.scan()
+        part = big.scan(j * n, (j + 1) * n)
+        assert (part["arcs"], part["chk"]) == (r["arcs"], r["chk"])
+    base.set_node_base(0)
+    b = big.split_by_bits(5)
+    parts = [big.scan(int(b[i]), int(b[i + 1])) for i in range(5)]
+    assert sum(p["arcs"] for p in parts) == whole["arcs"]
+    assert sum(p["chk"] for p in parts) % (1 << 64) == whole["chk"]
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    for j, lo, hi in ((K - 1, 1000, 1300), (K // 3, n - 200, n), (1, 0, 150)):
+        deg, succ = big.decode_range(j * n + lo, j * n + hi)
+        odeg, osucc = og.decode_range(lo, hi)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc + j * n)
+    # the oracle agrees with tile 0 as a whole
+    assert big.scan(0, n)["chk"] == og.scan()["chk"]
+
+
+def test_successors_batch_random_access(W, small, cnr_golden):
+    """Frontier-style random access: arbitrary order, repeats, chain heads and tails."""
+    g, og, lists, st = small
+    rng = np.random.default_rng(3)
+    nodes = np.concatenate([rng.integers(0, g.num_nodes(), 3000), [0, 0, g.num_nodes() - 1, 7, 6, 5, 4, 3, 2, 1]])
+    deg, succ = g.successors_batch(nodes)
+    assert deg.tolist() == [len(lists[x]) for x in nodes]
+    exp = [lists[x] for x in nodes if len(lists[x])]
+    assert np.array_equal(succ, np.concatenate(exp))
+    with pytest.raises(W.IllegalArgumentException):
+        g.successors_batch([0, g.num_nodes()])
+    d0, s0 = g.successors_batch([])
+    assert len(d0) == 0 and len(s0) == 0
+    c = W.BVGraph.load(CNR)
+    nodes = rng.integers(0, c.num_nodes(), 20000)
+    deg, succ = c.successors_batch(nodes)
+    assert np.array_equal(succ, np.concatenate([cnr_golden[x] for x in nodes]))
+    assert deg.tolist() == [len(cnr_golden[x]) for x in nodes]

@@ -112,6 +112,7 @@ def lib():
         L.bvg_decode_range.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
+        L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
         L.bvg_tile.argtypes = [vp, i64, pp]
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
@@ -388,6 +389,21 @@ class BVGraph:
                 continue
             _check(st, "decode_range(%d,%d)" % (frm, to))
             return deg[:cnt], succ[:need.value]
+
+    def successors_batch(self, nodes):
+        """successors(x) for a frontier: returns (outdeg int32[len(nodes)], succ int64[sum]) in request order."""
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        deg = np.empty(max(len(nodes), 1), dtype=np.int32)
+        need = C.c_uint64(0)
+        cap = max(1024, 16 * len(nodes))
+        while True:
+            succ = np.empty(cap, dtype=np.int64)
+            st = lib().bvg_successors_batch(self._h, nodes.ctypes.data if len(nodes) else None, len(nodes), deg.ctypes.data, succ.ctypes.data, cap, C.byref(need))
+            if st == _abi.E_CAPACITY:
+                cap = int(need.value)
+                continue
+            _check(st, "successors_batch")
+            return deg[:len(nodes)], succ[:need.value]
 
     def successor_array(self, x):
         if x < 0 or x >= self.num_nodes():

@@ -218,19 +218,27 @@ int build_plan(bvg_graph* g, uint32_t block_bits) {
 uint32_t block_bits_of(const bvg_graph* g) { return g->tun.block_bits ? g->tun.block_bits : kDefaultBlockBits; }
 
 // Runs the decode kernel over the blocks intersecting [from,to); slow-path relaunches included.
+// `batch` != nullptr: the blocks are the even entries of a per-call plan (one request each, bvg_successors_batch).
+struct BatchPlan { const uint64_t* d_first; const uint32_t* d_halo; const uint64_t* d_mask; uint32_t requests; };
+
 int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
-               bvg_scan_result* res) {
+               bvg_scan_result* res, const BatchPlan* batch = nullptr) {
     Shared* sh = g->sh;
-    int r = build_plan(g, block_bits_of(g)); if (r) return r;
+    int r = 0;
+    if (!batch) { r = build_plan(g, block_bits_of(g)); if (r) return r; }
     const Plan& pl = sh->plan;
     const bool wide = sh->wide || g->tun.force_wide;
     // block range
-    const std::vector<uint64_t>& hf = pl.h_first;
-    uint32_t lo = (uint32_t)(std::upper_bound(hf.begin(), hf.end(), (uint64_t)from) - hf.begin());
-    lo = lo ? lo - 1 : 0;
-    uint32_t hi = (uint32_t)(std::lower_bound(hf.begin(), hf.end(), (uint64_t)to) - hf.begin());
-    if (hi > pl.nblk) hi = pl.nblk;
-    uint32_t nblocks = hi > lo ? hi - lo : 0;
+    uint32_t lo = 0, nblocks = 0;
+    if (batch) nblocks = batch->requests;
+    else {
+        const std::vector<uint64_t>& hf = pl.h_first;
+        lo = (uint32_t)(std::upper_bound(hf.begin(), hf.end(), (uint64_t)from) - hf.begin());
+        lo = lo ? lo - 1 : 0;
+        uint32_t hi = (uint32_t)(std::lower_bound(hf.begin(), hf.end(), (uint64_t)to) - hf.begin());
+        if (hi > pl.nblk) hi = pl.nblk;
+        nblocks = hi > lo ? hi - lo : 0;
+    }
 
     if (nblocks > g->fail_cap) {                            // every block may fail over to the slow path
         (void)hipFree(g->d_fail); g->d_fail = nullptr;
@@ -243,7 +251,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     DecodeArgs a{};
     a.graph = sh->d_graph; a.limit_byte = sh->nbytes; a.padded_bytes = sh->padded; a.offsets = sh->d_offsets; a.n = sh->p.nodes;
     a.from = from; a.to = to;
-    a.blk_first = pl.d_first; a.blk_halo = pl.d_halo; a.blk_mask = pl.d_mask; a.work_list = nullptr; a.blk_lo = lo;
+    a.blk_first = batch ? batch->d_first : pl.d_first; a.blk_halo = batch ? batch->d_halo : pl.d_halo; a.blk_mask = batch ? batch->d_mask : pl.d_mask;
+    a.work_list = nullptr; a.blk_lo = lo; a.batch = batch ? 1u : 0u;
     a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
     a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
@@ -284,6 +293,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         return 0;
     };
 
+    auto upload_work = [&]() -> int {
+        if (d_work) { (void)hipFree(d_work); d_work = nullptr; }
+        HIPCHK(hipMalloc(&d_work, work.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(d_work, work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
+        a.work_list = d_work;
+        return 0;
+    };
     // ---- tier 0: every block, LDS sized for occupancy (the list pool holds one row of 64 lists + the window)
     if (nblocks && !g->tun.force_slow) {
         if (stream) {                                       // list ring: power of two
@@ -297,23 +314,20 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
         }
+        if (batch) {                                        // one block per request: the even entries of the per-call plan
+            work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = 2 * i;
+            r = upload_work(); if (r) return r;
+            work.clear();
+        }
         r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
                                               else if (legacy) launch_decode(a, nblocks, wide, materialise, false, g->stream);
                                               else launch_rows_decode(a, nblocks, wide, materialise, g->stream); });
         if (r) return r;
         launches++;
         r = fetch_failures(work); if (r) return r;
-    } else if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = lo + i; }
+    } else if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; }
     slow_blocks = (uint32_t)work.size();
 
-    auto upload_work = [&]() -> int {
-        if (d_work) { (void)hipFree(d_work); d_work = nullptr; }
-        HIPCHK(hipMalloc(&d_work, work.size() * sizeof(uint32_t)));
-        HIPCHK(hipMemcpy(d_work, work.data(), work.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
-        a.work_list = d_work;
-        return 0;
-    };
     // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with a pool sized to
     //      what each block reported it needs (size classes keep as many waves resident as possible)
     if (!work.empty() && !g->tun.force_slow) {
@@ -638,6 +652,47 @@ int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, in
 }
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ) {
     return decode_range_impl(g, from, to, (int32_t*)d_outdeg, (int64_t*)d_succ, succ_cap, n_succ, true);
+}
+
+int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
+    if (!g || (!nodes && count) || count < 0) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    for (int64_t i = 0; i < count; i++) if (nodes[i] < 0 || nodes[i] >= sh->p.nodes) return BVG_E_ARG;      // BVG:863
+    if (n_succ) *n_succ = 0;
+    if (count == 0) return 0;
+    if (count > 0x3FFFFFFF) return BVG_E_ARG;
+    HIPCHK(hipSetDevice(sh->device));
+    int64_t* d_nodes = nullptr; int32_t* d_deg = nullptr; uint64_t *d_first = nullptr, *d_cum = nullptr, *d_tmp = nullptr, *d_mask = nullptr;
+    uint32_t* d_halo = nullptr; int64_t* d_succ = nullptr;
+    auto cleanup = [&]() { for (void* p : {(void*)d_nodes, (void*)d_deg, (void*)d_first, (void*)d_cum, (void*)d_tmp, (void*)d_mask, (void*)d_halo, (void*)d_succ}) if (p) (void)hipFree(p); };
+#define SB_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP; } } while (0)
+    SB_CHK(hipMalloc(&d_nodes, (size_t)count * sizeof(int64_t)));
+    SB_CHK(hipMalloc(&d_deg, (size_t)count * sizeof(int32_t)));
+    SB_CHK(hipMalloc(&d_first, (2 * (size_t)count + 1) * sizeof(uint64_t)));
+    SB_CHK(hipMalloc(&d_cum, ((size_t)count + 1) * sizeof(uint64_t)));
+    SB_CHK(hipMalloc(&d_tmp, scan_tmp_elems(count) * sizeof(uint64_t)));
+    SB_CHK(hipMalloc(&d_halo, 2 * (size_t)count * sizeof(uint32_t)));
+    SB_CHK(hipMalloc(&d_mask, 2 * (size_t)count * sizeof(uint64_t)));
+    SB_CHK(hipMemcpyAsync(d_nodes, nodes, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
+    launch_outdegrees_gather(sh->d_graph, sh->nbytes, sh->d_offsets, d_nodes, count, sh->p.outdegree_coding, d_deg, d_first, g->stream);
+    launch_exclusive_scan(d_deg, d_cum, count, d_tmp, g->stream);
+    launch_plan_halo(sh->d_graph, sh->nbytes, sh->d_offsets, sh->p.nodes, d_first, (uint32_t)(2 * count), sh->p.window_size, codings_of(sh->p), d_halo, d_mask, g->stream);
+    uint64_t total = 0;
+    std::vector<uint32_t> halo(2 * (size_t)count);
+    SB_CHK(hipMemcpyAsync(&total, d_cum + count, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    SB_CHK(hipMemcpyAsync(halo.data(), d_halo, halo.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+    SB_CHK(hipStreamSynchronize(g->stream));
+    if (n_succ) *n_succ = total;
+    if (outdeg) SB_CHK(hipMemcpy(outdeg, d_deg, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (total > succ_cap || (!succ && total > 0)) { cleanup(); return BVG_E_CAPACITY; }
+    for (int64_t i = 0; i < count; i++) if (halo[2 * (size_t)i] == 0xFFFFFFFFu) { cleanup(); return BVG_E_UNSUPPORTED; }   // reference chain > 64 nodes back
+    SB_CHK(hipMalloc(&d_succ, (size_t)(total ? total : 1) * sizeof(int64_t)));
+    BatchPlan bp{d_first, d_halo, d_mask, (uint32_t)count};
+    int rc = run_decode(g, 0, sh->p.nodes, true, d_cum, d_succ, nullptr, nullptr, &bp);
+    if (rc == 0 && total) SB_CHK(hipMemcpy(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
+    cleanup();
+#undef SB_CHK
+    return rc;
 }
 
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) {

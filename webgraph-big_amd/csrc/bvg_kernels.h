@@ -39,6 +39,7 @@ struct DecodeArgs {
     uint32_t lds_pool_elems, lds_scr_elems;
     uint32_t lds_stage_words;           // row-static kernel: LDS window over the stream, in dwords (multiple of 4)
     uint32_t grab_threshold;            // stream kernel: idle lanes that trigger a batched grab
+    uint32_t batch;                     // 1 = bvg_successors_batch: block 2i is request i; outputs are indexed by request
     uint32_t dbg;                       // timing experiments only (BVG_DBG): 1 skip emission, 2 skip residual decode, 4 skip parse
 };
 
@@ -51,6 +52,9 @@ void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool
 // thread per node: outdegree (BVG:821-842)
 void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,
                        int outdegree_coding, int32_t* out, unsigned long long* total, hipStream_t s);
+// outdegree of an arbitrary list of nodes (random access, BVG:821-842); also writes the two plan entries {x, x+1} per request
+void launch_outdegrees_gather(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const int64_t* nodes, int64_t count,
+                              int outdegree_coding, int32_t* out, uint64_t* first, hipStream_t s);
 // exclusive prefix sum of int32 -> uint64 (n+1 outputs), single stream, hand-written 3-phase scan
 void launch_exclusive_scan(const int32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s);
 size_t scan_tmp_elems(int64_t n);

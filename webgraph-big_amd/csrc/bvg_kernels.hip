@@ -286,12 +286,12 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 const int lb = 63 - __clzll(repmask);
                 const uint64_t seg0 = __shfl(base, la, 64);
                 const uint64_t seg1 = __shfl(base + d, lb, 64);
-                const uint64_t dst0 = a.cum[(r0 + la) - a.from];
+                const uint64_t dst0 = a.batch ? a.cum[bid >> 1] : a.cum[(r0 + la) - a.from];
                 for (uint64_t t = lane; t < seg1 - seg0; t += 64) {
                     const T v = pool[seg0 + t];
                     a.succ[dst0 + t] = v == sentinel<T>() ? -1ll : (int64_t)((uint64_t)v + a.node_base);
                 }
-                if (rep && a.outdeg) a.outdeg[x - a.from] = (int32_t)d;
+                if (rep && a.outdeg && !a.batch) a.outdeg[x - a.from] = (int32_t)d;
             }
         }
         __syncthreads();
@@ -329,6 +329,16 @@ __global__ void outdegree_kernel(const uint8_t* graph, uint64_t limit_byte, cons
         d = wave_sum64(d);
         if ((threadIdx.x & 63) == 0 && d) atomicAdd(total, (unsigned long long)d);
     }
+}
+
+__global__ void outdegree_gather_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const int64_t* nodes, int64_t count,
+                                        int coding, int32_t* out, uint64_t* first) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t x = nodes[i];
+    BitCursor cur{graph, offsets[x], limit_byte};
+    out[i] = (int32_t)cur.read_coded(coding, 0, offsets[x + 1]);
+    first[2 * i] = (uint64_t)x; first[2 * i + 1] = (uint64_t)x + 1;
 }
 
 // ---- exclusive scan int32 -> uint64, three phases, 1024 elements per workgroup ----
@@ -480,6 +490,12 @@ void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t
     int64_t n = to - from;
     if (n <= 0) return;
     hipLaunchKernelGGL(outdegree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, graph, limit_byte, offsets, from, to, coding, out, total);
+}
+
+void launch_outdegrees_gather(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const int64_t* nodes, int64_t count,
+                              int coding, int32_t* out, uint64_t* first, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(outdegree_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, graph, limit_byte, offsets, nodes, count, coding, out, first);
 }
 
 size_t scan_tmp_elems(int64_t n) { return (size_t)((n + kScanTile - 1) / kScanTile) + 1; }

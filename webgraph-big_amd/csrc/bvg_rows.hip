@@ -327,12 +327,12 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 const int lb = 63 - __clzll(repmask);
                 const uint32_t seg0 = __shfl(base, la, 64);
                 const uint32_t seg1 = __shfl(base + d, lb, 64);
-                const uint64_t dst0 = a.cum[(r0 + la) - a.from];
+                const uint64_t dst0 = a.batch ? a.cum[bid >> 1] : a.cum[(r0 + la) - a.from];
                 for (uint32_t t = lane; t < seg1 - seg0; t += 64) {
                     const T vv = pool[seg0 + t];
                     a.succ[dst0 + t] = vv == sentinel<T>() ? -1ll : (int64_t)((uint64_t)vv + a.node_base);
                 }
-                if (rep && a.outdeg) a.outdeg[x - a.from] = (int32_t)d;
+                if (rep && a.outdeg && !a.batch) a.outdeg[x - a.from] = (int32_t)d;
             }
         }
         __syncthreads();

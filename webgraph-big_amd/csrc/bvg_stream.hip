@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
                         m_nr[slot] = h_nr; m_pr[slot] = rel; m_pe[slot] = pend;
                         const bool prep = px >= rep_lo && px < rep_hi;
                         if (!MAT) { const uint64_t kx = splitmix64((uint64_t)(hs + px) + a.node_base); m_k0[slot] = (uint32_t)kx; m_k1[slot] = (uint32_t)(kx >> 32) | 1u; }
-                        else m_out[slot] = prep ? a.cum[hs + px - a.from] : 0;
+                        else m_out[slot] = prep ? (a.batch ? a.cum[bid >> 1] : a.cum[hs + px - a.from]) : 0;
                     }
                     if (ballot(bad)) { failed = true; break; }
                     bhead += btot;
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
                     ivrem = 0; ivfirst = true; rvalid = false; rfirst = true;
                     if (rep) {
                         if (!MAT) { k0 = m_k0[cs]; k1 = m_k1[cs]; }
-                        else { out0 = m_out[cs]; if (a.outdeg) a.outdeg[hs + cand - a.from] = (int32_t)cd; }
+                        else { out0 = m_out[cs]; if (a.outdeg && !a.batch) a.outdeg[hs + cand - a.from] = (int32_t)cd; }
                         acc_arcs += cd; acc_nodes += 1;
                     }
                 }
