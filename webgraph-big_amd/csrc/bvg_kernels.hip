@@ -244,12 +244,11 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
         T rhead = nres ? out[d - nres] : sentinel<T>();
         uint32_t j = 0;
         uint64_t chk = 0;
-        volatile uint32_t* vprod = produced;
         for (;;) {
             const bool todo = act && j < d;
             if (!ballot(todo)) break;
             const bool cneed = todo && rpos < rlen;
-            const bool cready = !cneed || rlane < 0 || vprod[rlane] > rpos;
+            const bool cready = !cneed || rlane < 0 || __hip_atomic_load(&produced[rlane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) > rpos;
             if (todo && cready) {
                 const T c = cneed ? rl[rpos] : sentinel<T>();
                 const T iv = ivrem ? ivcur : sentinel<T>();
@@ -272,7 +271,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                     if (--ivrem == 0 && ivi < ic) { ivcur = scr[ib + 2 * ivi]; ivrem = (uint32_t)scr[ib + 2 * ivi + 1]; ivi++; }
                 }
                 if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? out[d - nres + rsi] : sentinel<T>(); }
-                vprod[lane] = j;
+                __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
         if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }

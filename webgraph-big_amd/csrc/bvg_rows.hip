@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint32_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
-    __shared__ uint32_t produced[64];
+    __shared__ uint32_t produced[64];             // read/written with wavefront-scope relaxed atomics: plain ds_read/ds_write that
+                                                  // the compiler may not cache (a `volatile` here compiles to flat sc0 sc1 + vmcnt(0))
     __shared__ uint32_t scr_used;
 
     const unsigned lane = threadIdx.x;
@@ -282,13 +283,12 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
         T rhead = nres ? out[d - nres] : sentinel<T>();
         uint32_t j = 0;
         uint64_t chk = 0;
-        volatile uint32_t* vprod = produced;
         for (;;) {
             const bool todo = act && j < d && !(a.dbg & 1);
             if (!ballot(todo)) break;
             const bool cneed = todo && rpos < rlen;
             // both loads are issued together; the copy head is only used when the producer is far enough
-            const uint32_t pr = vprod[rlane];
+            const uint32_t pr = __hip_atomic_load(&produced[rlane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             const T cval = rl[cneed ? rpos : 0];
             const bool cready = !cneed || !samerow || pr > rpos;
             if (todo && cready) {
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 T m = c < iv ? c : iv; m = m < rhead ? m : rhead;             // MergedLongIterator.java:63-92, three-way
                 out[j] = m;
                 j++;
-                vprod[lane] = j;
+                __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (!MAT && rep) {
                     const uint64_t y64 = m == sentinel<T>() ? ~0ull : (uint64_t)m + a.node_base;
                     chk += mix_keyed(k0, k1, y64);

@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
             // ---- merge step: emit one successor (MergedLongIterator.java:63-92, three-way)
             {
                 const bool chas = busy && cpos < clen && keep != 0;
-                const bool blocked = (busy && cpos < clen && keep == 0) || (chas && ((volatile uint32_t*)nd_prod)[cslot] <= cpos);
+                const bool blocked = (busy && cpos < clen && keep == 0) || (chas && __hip_atomic_load(&nd_prod[cslot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) <= cpos);
                 const bool can = busy && !blocked && (rvalid || nr == 0) && (ivrem != 0 || ni == 0);
                 const T c = chas ? pool[(cb + cpos) & PM] : sentinel<T>();
                 const T iv = ivrem ? ivcur : sentinel<T>();
@@ -379,7 +379,7 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
                         else a.succ[out0 + j] = m == sentinel<T>() ? -1ll : (int64_t)y64;
                     }
                     j++;
-                    ((volatile uint32_t*)nd_prod)[myslot] = j;
+                    __hip_atomic_store(&nd_prod[myslot], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const bool ec = chas && c == m, ei = ivrem != 0 && iv == m, er = rvalid && r == m;
                     cpos += ec ? 1u : 0u; keep -= ec ? 1u : 0u;
                     ivcur += ei ? 1 : 0; ivrem -= ei ? 1u : 0u;
