@@ -3,7 +3,9 @@ run() { timeout 300 python bench.py --shape $1 --steps 2 --warmup 1 --target-gib
 import sys,json
 t=[]
 for l in sys.stdin:
-    if l.startswith('[bvg]'): t.append(l.split(':')[0].replace('[bvg] ','')+'='+l.split(',')[-1].strip())
+    if l.startswith('[bvg]'): t.append(l.strip().replace('[bvg] ',''))
     else:
-        d=json.loads(l); print('%.1f Gedges/s kernel %.1f ms slow %d'%(d['value']/1e9, d['roofline']['kernel_ms'], d['slow_blocks']), ' '.join(t[-5:]))"; }
-for sh in web eu w0; do echo "$sh rows : $(run $sh)"; echo "$sh stream : $(run $sh --stream)"; done
+        d=json.loads(l); print('%.1f Gedges/s kernel %.1f ms slow %d'%(d['value']/1e9, d['roofline']['kernel_ms'], d['slow_blocks']), ' | '.join(t[-3:]))"; }
+for sh in web eu w0; do echo "$sh : $(run $sh)"; done
+export BVG_NOPREDICT=1
+for sh in web eu; do echo "$sh nopredict : $(run $sh)"; done

@@ -40,11 +40,13 @@ struct Plan {
     uint32_t nblk = 0;
     uint64_t* d_first = nullptr; uint32_t* d_halo = nullptr; uint64_t* d_mask = nullptr;
     std::vector<uint64_t> h_first;
+    std::vector<uint32_t> h_maxd;             // largest (list + the W lists before it) a block decodes: predicts its tier
+    uint64_t version = 0;
     void release() {
         if (d_first) (void)hipFree(d_first);
         if (d_halo) (void)hipFree(d_halo);
         if (d_mask) (void)hipFree(d_mask);
-        d_first = nullptr; d_halo = nullptr; d_mask = nullptr; nblk = 0; h_first.clear();
+        d_first = nullptr; d_halo = nullptr; d_mask = nullptr; nblk = 0; h_first.clear(); h_maxd.clear();
     }
 };
 
@@ -71,6 +73,10 @@ struct bvg_graph {
     uint64_t node_base = 0;
     bvg_tuning tun{};
     void* slow_ws = nullptr; uint64_t slow_ws_bytes = 0;   // tier-2 (global-memory) pools, kept between calls
+    // predicted tiers run concurrently with tier 0 on high-priority side streams (their few, long blocks are the critical path)
+    hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t side_ev[2] = {nullptr, nullptr};
+    void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
+    struct Pred { uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0; } pred;
 };
 
 namespace {
@@ -135,6 +141,14 @@ int make_handle(Shared* sh, bvg_graph** out) {
     g->sh = sh;
     HIPCHK(hipSetDevice(sh->device));
     HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipStreamCreateWithPriority(&g->side[i], hipStreamNonBlocking, greatest));
+            HIPCHK(hipEventCreateWithFlags(&g->side_ev[i], hipEventDisableTiming));
+        }
+    }
     HIPCHK(hipEventCreate(&g->ev0));
     HIPCHK(hipEventCreate(&g->ev1));
     HIPCHK(hipMalloc(&g->d_acc, 4 * sizeof(unsigned long long)));
@@ -203,6 +217,18 @@ int build_plan(bvg_graph* g, uint32_t block_bits) {
             if (any_bad) { (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask); return BVG_E_UNSUPPORTED; }
             sh->plan.d_first = d_first; sh->plan.d_halo = d_halo; sh->plan.d_mask = d_mask;
             sh->plan.nblk = nblk; sh->plan.h_first = uniq;
+            {   // per-block largest outdegree (one wavefront per block), kept on the host to predict tiers
+                uint32_t* d_maxd = nullptr;
+                HIPCHK(hipMalloc(&d_maxd, (size_t)nblk * sizeof(uint32_t)));
+                launch_plan_maxd(sh->d_graph, limit, sh->d_offsets, d_first, d_halo, nblk, sh->p.outdegree_coding, sh->p.window_size, d_maxd, g->stream);
+                sh->plan.h_maxd.resize(nblk);
+                hipError_t e2 = hipMemcpyAsync(sh->plan.h_maxd.data(), d_maxd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(g->stream);
+                (void)hipFree(d_maxd);
+                if (e2 != hipSuccess) return BVG_E_HIP;
+            }
+            static std::atomic<uint64_t> plan_versions{1};
+            sh->plan.version = plan_versions.fetch_add(1);
             return 0;
         }
         // merge blocks: drop un-cuttable boundaries (the halo of a kept boundary does not depend on the others)
@@ -319,14 +345,99 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             r = upload_work(); if (r) return r;
             work.clear();
         }
+        const uint32_t max_pool = wide ? 6144 : 12288;
+        const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
+        const bool predict = !batch && !stream && !legacy && pl.h_maxd.size() == pl.nblk && !getenv("BVG_NOPREDICT");
+        if (predict) {
+            // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
+            bvg_graph::Pred& pd = g->pred;
+            const uint32_t pool0 = a.lds_pool_elems;
+            if (pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || !pd.d_lists) {
+                std::vector<uint32_t> L[6];
+                uint64_t gneed = 0;
+                for (uint32_t i = 0; i < nblocks; i++) {
+                    const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
+                    const bool long_record = (pl.h_maxd[lo + i] >> 31) != 0;
+                    const uint64_t need = md + md / 8 + 64;
+                    int c;
+                    if (long_record) c = 5;
+                    else if (need <= pool0) c = 0;
+                    else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
+                    if (c == 5 && need > gneed) gneed = need;
+                    L[c].push_back(lo + i);
+                }
+                if (pd.d_lists) { (void)hipFree(pd.d_lists); pd.d_lists = nullptr; }
+                HIPCHK(hipMalloc(&pd.d_lists, (size_t)nblocks * sizeof(uint32_t)));
+                size_t off = 0;
+                for (int c = 0; c < 6; c++) {
+                    pd.count[c] = (uint32_t)L[c].size();
+                    if (!L[c].empty()) HIPCHK(hipMemcpy(pd.d_lists + off, L[c].data(), L[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                    off += L[c].size();
+                }
+                pd.plan_version = pl.version; pd.lo = lo; pd.n = nblocks; pd.pool0 = pool0; pd.giant_need = gneed;
+            }
+            // giants: global-memory pools sized to the largest list, allocated before anything is launched
+            uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0;
+            if (pd.count[5]) {
+                gpool_elems = 1ull << 16; while (gpool_elems < pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(pd.count[5], 256);
+                const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
+                if (bytes > g->giant_ws_bytes) {
+                    if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
+                    if (hipMalloc(&g->giant_ws, bytes) == hipSuccess) g->giant_ws_bytes = bytes; else gbatch = 0;   // fall back to the cascade
+                }
+            }
+            HIPCHK(hipEventRecord(g->ev0, g->stream));
+            HIPCHK(hipStreamWaitEvent(g->side[0], g->ev0, 0));
+            HIPCHK(hipStreamWaitEvent(g->side[1], g->ev0, 0));
+            size_t off = 0;
+            DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
+            off += pd.count[0];
+            size_t offc[6]; { size_t o = 0; for (int c = 0; c < 6; c++) { offc[c] = o; o += pd.count[c]; } }
+            if (pd.count[5] && gbatch) {                                       // giants first: they are the critical path
+                DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
+                ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
+                for (uint32_t o2 = 0; o2 < pd.count[5]; o2 += gbatch) {
+                    ag.work_list = pd.d_lists + offc[5] + o2;
+                    launch_decode(ag, std::min<uint32_t>(gbatch, pd.count[5] - o2), wide, materialise, true, g->side[1]);
+                    launches++;
+                }
+            }
+            for (int c = 4; c >= 1; c--) {                                     // LDS size classes, largest first
+                if (!pd.count[c]) continue;
+                DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
+                ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
+                launch_rows_decode(ac, pd.count[c], wide, materialise, g->side[0]);
+                launches++;
+            }
+            if (pd.count[0]) { launch_rows_decode(a0, pd.count[0], wide, materialise, g->stream); launches++; }
+            HIPCHK(hipEventRecord(g->side_ev[0], g->side[0]));
+            HIPCHK(hipEventRecord(g->side_ev[1], g->side[1]));
+            HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[0], 0));
+            HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[1], 0));
+            HIPCHK(hipEventRecord(g->ev1, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+            kernel_ms += ms;
+            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant blocks, %.3f ms\n",
+                                             pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], ms);
+            slow_blocks = nblocks - pd.count[0];
+            if (pd.count[5] && !gbatch) {                                      // could not get the giant workspace: leave them to the cascade
+                std::vector<uint32_t> gl(pd.count[5]);
+                HIPCHK(hipMemcpy(gl.data(), pd.d_lists + offc[5], gl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                r = fetch_failures(work); if (r) return r;
+                work.insert(work.end(), gl.begin(), gl.end());
+            } else { r = fetch_failures(work); if (r) return r; }
+        } else {
         r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
                                               else if (legacy) launch_decode(a, nblocks, wide, materialise, false, g->stream);
                                               else launch_rows_decode(a, nblocks, wide, materialise, g->stream); });
         if (r) return r;
         launches++;
         r = fetch_failures(work); if (r) return r;
-    } else if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; }
-    slow_blocks = (uint32_t)work.size();
+        slow_blocks = (uint32_t)work.size();
+        }
+    } else if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; slow_blocks = nblocks; }
 
     // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with a pool sized to
     //      what each block reported it needs (size classes keep as many waves resident as possible)
@@ -336,16 +447,17 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const uint32_t max_pool = wide ? 6144 : 12288;
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
         std::vector<uint32_t> bins[4], rest;
+        if (getenv("BVG_DEBUG")) { size_t h[8] = {0}; for (uint32_t nd : need) h[nd >= 0xFFFFFFF0u ? (nd & 7) : 0]++; fprintf(stderr, "[bvg] failures: pool %zu, window %zu, huge %zu, blocks-scratch %zu, intervals-scratch %zu, code %zu, other %zu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[7]); }
         for (size_t i = 0; i < work.size(); i++) {
             int c = 3;
-            if (!stream && !legacy && need[i] != 0xFFFFFFFFu) { c = 0; while (c < 3 && classes[c] < need[i]) c++; if (classes[c] < need[i]) c = -1; }
+            if (!stream && !legacy && need[i] < 0xFFFFFFF0u) { c = 0; while (c < 3 && classes[c] < need[i]) c++; if (classes[c] < need[i]) c = -1; }
             if (c < 0) rest.push_back(work[i]); else bins[c].push_back(work[i]);
         }
         for (int c = 0; c < 4; c++) {
             if (bins[c].empty()) continue;
             work.swap(bins[c]);
             r = upload_work(); if (r) return r;
-            a.lds_pool_elems = classes[c]; a.lds_scr_elems = std::max<uint32_t>(512, classes[c] / 8); a.lds_stage_words = 1024;
+            a.lds_pool_elems = classes[c]; a.lds_scr_elems = std::max<uint32_t>(1024, classes[c] / 4); a.lds_stage_words = 1024;
             const uint32_t nb = (uint32_t)work.size();
             r = timed("tier1 (big LDS)", nb, [&] { if (legacy) launch_decode(a, nb, wide, materialise, false, g->stream); else launch_rows_decode(a, nb, wide, materialise, g->stream); });
             if (r) return r;
@@ -577,6 +689,9 @@ void bvg_close(bvg_graph* g) {
     if (g->d_acc) (void)hipFree(g->d_acc);
     if (g->d_fail) (void)hipFree(g->d_fail);
     if (g->slow_ws) (void)hipFree(g->slow_ws);
+    if (g->giant_ws) (void)hipFree(g->giant_ws);
+    if (g->pred.d_lists) (void)hipFree(g->pred.d_lists);
+    for (int i = 0; i < 2; i++) { if (g->side[i]) { (void)hipStreamSynchronize(g->side[i]); (void)hipStreamDestroy(g->side[i]); } if (g->side_ev[i]) (void)hipEventDestroy(g->side_ev[i]); }
     release_shared(g->sh);
     delete g;
 }

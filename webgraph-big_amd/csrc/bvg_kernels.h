@@ -64,6 +64,10 @@ void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_b
 void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first, uint32_t nblk,
                       int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s);
 
+// plan: largest outdegree among the nodes a block decodes (its own + its halo): predicts the LDS tier it needs
+void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
+                      int outdegree_coding, int window, uint32_t* maxd, hipStream_t s);
+
 // synthetic tiling (bvg_tile)
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
 void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);

@@ -421,6 +421,43 @@ __global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, cons
     mask[k] = m;
 }
 
+// one wavefront per block: lanes stride over the block's nodes (coalesced offsets reads); the value kept is
+// the largest "own list + the W lists before it" — what the LDS pool must hold to decode that node at all
+__global__ void plan_maxd_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo,
+                                 uint32_t nblk, int coding, int window, uint32_t* maxd) {
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= nblk) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const uint32_t h = halo[k] == 0xFFFFFFFFu ? 0u : halo[k];
+    const int64_t lo = (int64_t)first[k] - (int64_t)h, hi = (int64_t)first[k + 1];
+    uint64_t m = 0, mrec = 0;
+    uint32_t prevd = 0;                                                       // d of node x-64 (previous chunk, same lane)
+    for (int64_t x0 = lo; x0 < hi; x0 += 64) {
+        const int64_t x = x0 + lane;
+        uint32_t dd = 0;
+        if (x < hi) {
+            BitCursor cur{graph, offsets[x], limit_byte};
+            const uint64_t end = offsets[x + 1];
+            const uint64_t d = cur.read_coded(coding, 0, end);
+            dd = d > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)d;
+            const uint64_t rec = end - offsets[x];
+            mrec = rec > mrec ? rec : mrec;
+        }
+        uint64_t need = dd;
+        for (int j = 1; j <= window && j < 64; j++) {
+            const uint32_t a = __shfl_up(dd, j, 64);                           // same chunk
+            const uint32_t b = __shfl(prevd, (int)((lane + 64 - j) & 63), 64); // previous chunk
+            need += (int)lane >= j ? a : b;
+        }
+        if (x < hi) m = need > m ? need : m;
+        prevd = dd;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint64_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; const uint64_t t2 = __shfl_xor(mrec, o, 64); mrec = t2 > mrec ? t2 : mrec; }
+    // bit 31 flags a record longer than the largest LDS stream window (4 KiB): such a block goes straight to the global tier
+    if (lane == 0) maxd[k] = (m > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)m) | (mrec + 128 > 32768 ? 0x80000000u : 0u);
+}
+
 // ---- synthetic tiling ----
 __device__ __forceinline__ uint64_t load_bits64(const uint8_t* src, uint64_t bitpos) {
     const uint8_t* p = src + (bitpos >> 3);
@@ -515,6 +552,12 @@ void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t*
                       int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s) {
     if (!nblk) return;
     hipLaunchKernelGGL(plan_halo_kernel, dim3((nblk + 127) / 128), dim3(128), 0, s, graph, limit_byte, offsets, n, first, nblk, window, cod, halo, mask);
+}
+
+void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
+                      int coding, int window, uint32_t* maxd, hipStream_t s) {
+    if (!nblk) return;
+    hipLaunchKernelGGL(plan_maxd_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, graph, limit_byte, offsets, first, halo, nblk, coding, window, maxd);
 }
 
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s) {

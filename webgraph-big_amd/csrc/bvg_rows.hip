@@ -48,7 +48,6 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
     __shared__ uint32_t nd_d[kRing];
     __shared__ uint32_t produced[64];             // read/written with wavefront-scope relaxed atomics: plain ds_read/ds_write that
                                                   // the compiler may not cache (a `volatile` here compiles to flat sc0 sc1 + vmcnt(0))
-    __shared__ uint32_t scr_used;
 
     const unsigned lane = threadIdx.x;
     const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
@@ -116,7 +115,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
             kwin = m == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~m) - 1u;
             if (kwin > left) kwin = left;
         }
-        if (kwin == 0) { failed = true; break; }                              // a single record larger than the window
+        if (kwin == 0) { failed = true; fail_need = 0xFFFFFFF1u; break; }      // a single record larger than the window
         uint32_t rel = (uint32_t)(off_x - stg_bit0);                          // bit cursor relative to the window
         const uint32_t pend = (uint32_t)(rec_end - stg_bit0);
         bool bad = false;
@@ -153,28 +152,23 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
         if (total > avail) { const uint32_t kf = (uint32_t)__popcll(ballot(incl <= avail)); k = kf < k ? kf : k; }
         if (k == 0) {                                                         // first node alone overflows the pool
             failed = true;
-            if (kwin) { const uint32_t d0 = __shfl(d, 0, 64); fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFFFu : d0 + pool_used + (d0 >> 2) + 64; }
+            if (kwin) { const uint32_t d0 = __shfl(d, 0, 64); fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64; }
             break;
         }
-        const bool act = needed && lane < k;
         const uint32_t base = pool_used + (incl - dclamp);
-        if (act) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
-        pool_used += __shfl(incl, (int)k - 1, 64);
-        if (lane == 0) scr_used = 0;
-        produced[lane] = act ? 0u : kInf;
-        // prefetch the next row's offsets (their latency hides behind this row's decode)
-        uint64_t nxt_off = 0, nxt_end = 0;
-        {
-            const int64_t nx = r0 + k + lane;
-            if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
-        }
+        if (needed && lane < k) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
         __syncthreads();
 
         // ------------------------------------------------------------------ phase 1: parse own record
+        // Steps A..D with two wave-uniform points where the scratch area (copy blocks, then intervals) is
+        // allocated by prefix sums; lanes whose entries do not fit are cut from the row (k shrinks) and
+        // their nodes are simply parsed again at the head of the next row.
         uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
-        bool overflow = false;
-        if (act && d > 0 && !(a.dbg & 4)) {
-            if (W > 0) {                                                      // BVG:1015; readReference, BVG:692-703
+        int64_t extra = d;
+        const bool parse = needed && lane < k && d > 0 && !(a.dbg & 4);
+        // ---- A: reference and block count (BVG:1015-1021)
+        if (parse) {
+            if (W > 0) {                                                      // readReference, BVG:692-703
                 const uint64_t w = win64<LIN>(stage, rel);
                 uint32_t l;
                 if (GEN) l = decode_generic_w(w, a.cod.reference, 0, &v);
@@ -183,13 +177,20 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 if (v > W || (int64_t)v > x) { err |= ERR_REF_RANGE; v = 0; }
                 ref = (uint32_t)v;
             }
-            int64_t extra = d;
-            if (ref > 0) {                                                    // BVG:1020-1032
+            if (ref > 0) {                                                    // readBlockCount, BVG:728-735
                 const uint64_t w = win64<LIN>(stage, rel);
                 const uint32_t l = GEN ? decode_generic_w(w, a.cod.block_count, 0, &v) : gamma64(w, v);
                 bad |= l == 0 || v > pend - rel + 1; rel += l; bc = bad ? 0u : (uint32_t)v;
-                sb = atomicAdd(&scr_used, bc);
-                if (sb + bc > SCR) { overflow = true; bc = 0; }
+            }
+        }
+        const uint32_t bincl = wave_incl_scan32(bc > SCR ? SCR + 1 : bc);
+        { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCR)); k = kb < k ? kb : k; }
+        if (k == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }        // one node's copy blocks exceed the scratch area
+        sb = bincl - bc;
+        const uint32_t btot = __shfl(bincl, (int)k - 1, 64);
+        // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
+        if (parse && lane < k) {
+            if (ref > 0) {
                 int64_t copied = 0, tot = 0;
                 for (uint32_t i = 0; i < bc; i++) {
                     const uint64_t wb = win64<LIN>(stage, rel);
@@ -205,11 +206,28 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 extra = (int64_t)d - copied;
                 if (extra < 0 || copied < 0) { err |= ERR_MALFORMED; extra = 0; }       // never let a tail start before the list
             }
-            if (extra > 0 && minint != 0) {                                   // BVG:1037-1060 (always gamma)
-                uint32_t l = gamma64(win64<LIN>(stage, rel), v);
+            if (extra > 0 && minint != 0) {                                   // always gamma
+                const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
                 bad |= l == 0 || v > (pend - rel) / 2 + 1; rel += l; ic = bad ? 0u : (uint32_t)v;
-                ib = atomicAdd(&scr_used, 2 * ic);
-                if (ib + 2 * ic > SCR) { overflow = true; ic = 0; }
+            }
+        }
+        const uint32_t iw = lane < k ? 2 * ic : 0u;
+        const uint32_t iincl = wave_incl_scan32(iw > SCR ? SCR + 1 : iw);
+        { const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR)); k = ki < k ? ki : k; }
+        if (k == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }        // one node's intervals exceed the scratch area
+        ib = btot + iincl - iw;
+        const bool act = needed && lane < k;
+        pool_used += __shfl(incl, (int)k - 1, 64);
+        produced[lane] = act ? 0u : kInf;
+        // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
+        uint64_t nxt_off = 0, nxt_end = 0;
+        {
+            const int64_t nx = r0 + k + lane;
+            if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
+        }
+        // ---- D: intervals (BVG:1042-1058) and residuals (ResidualLongIterator, BVG:902-935)
+        if (parse && lane < k) {
+            if (ic > 0) {
                 int64_t prev = 0;
                 for (uint32_t i = 0; i < ic; i++) {
                     uint64_t v1, v2;
@@ -226,7 +244,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
             }
             nres = (uint32_t)extra;
-            if (nres > 0 && !overflow && !bad && !(a.dbg & 2)) {                              // ResidualLongIterator, BVG:902-935
+            if (nres > 0 && !bad && !(a.dbg & 2)) {
                 T* const tail = pool + base + d - nres;
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
@@ -253,9 +271,9 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                     if (rel > pend) { err |= ERR_OVERRUN; break; }
                 }
             }
-            if (rel != pend && !overflow && !bad && !a.dbg) err |= ERR_MALFORMED;      // SURVEY A.6 self-check
-        } else if (act && rel != pend && !bad) err |= ERR_MALFORMED;
-        if (ballot(overflow || bad)) { failed = true; break; }
+            if (rel != pend && !bad && !a.dbg) err |= ERR_MALFORMED;         // SURVEY A.6 self-check
+        } else if (act && d == 0 && rel != pend && !bad) err |= ERR_MALFORMED;
+        if (ballot(bad && lane < k)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
         __syncthreads();
 
         // ------------------------------------------------------------------ phase 2: data-flow emission
