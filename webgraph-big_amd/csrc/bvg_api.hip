@@ -335,7 +335,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (getenv("BVG_POOL")) cap = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)cap; a.lds_scr_elems = 0;
         } else {
-            uint64_t pool = ((uint64_t)(avg * 56.0) + 255) & ~255ull;   // ~a row of 64 lists (rows shrink when they do not fit)
+            uint64_t pool = ((uint64_t)(avg * 48.0) + 255) & ~255ull;   // ~a row of lists (rows shrink when they do not fit)
             pool = std::min<uint64_t>(std::max<uint64_t>(pool, 1024), wide ? 4096 : 8192);
             if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);

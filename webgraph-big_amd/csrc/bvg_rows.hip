@@ -22,6 +22,10 @@
 #include "bvg_kernels.h"
 #include "bvg_lds_codes.h"
 
+#ifndef BVG_ROWS_WAVES
+#define BVG_ROWS_WAVES 6
+#endif
+
 namespace bvg {
 
 namespace {
@@ -42,7 +46,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) {
 }
 
 template <typename T, bool MAT, bool GEN>
-__global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
+__global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint32_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
@@ -67,6 +71,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = !GEN && zk >= 2;
+    constexpr bool LEAN = !MAT;                              // scan mode: unreferenced lists are not materialised
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
     __syncthreads();
@@ -148,15 +153,15 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
             avail = CAP - pool_used;
             __syncthreads();
         }
+        // Scan mode stores a merged list only if a later node can copy from it (LEAN): the row is first sized
+        // optimistically on the outdegrees and cut to what really fits once the references are known.
         uint32_t k = kwin;
-        if (total > avail) { const uint32_t kf = (uint32_t)__popcll(ballot(incl <= avail)); k = kf < k ? kf : k; }
-        if (k == 0) {                                                         // first node alone overflows the pool
-            failed = true;
-            if (kwin) { const uint32_t d0 = __shfl(d, 0, 64); fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64; }
-            break;
+        {
+            const uint32_t budget = LEAN ? avail + (avail >> 1) : avail;
+            if (total > budget) { const uint32_t kf = (uint32_t)__popcll(ballot(incl <= budget)); k = kf < k ? kf : k; }
+            if (k == 0) k = 1;                                                // the exact check follows the header parse
         }
-        const uint32_t base = pool_used + (incl - dclamp);
-        if (needed && lane < k) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
+        if (needed && lane < k) nd_d[(uint32_t)x & RM] = d;
         __syncthreads();
 
         // ------------------------------------------------------------------ phase 1: parse own record
@@ -216,16 +221,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
         { const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR)); k = ki < k ? ki : k; }
         if (k == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }        // one node's intervals exceed the scratch area
         ib = btot + iincl - iw;
-        const bool act = needed && lane < k;
-        pool_used += __shfl(incl, (int)k - 1, 64);
-        produced[lane] = act ? 0u : kInf;
-        // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
-        uint64_t nxt_off = 0, nxt_end = 0;
-        {
-            const int64_t nx = r0 + k + lane;
-            if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
-        }
-        // ---- D: intervals (BVG:1042-1058) and residuals (ResidualLongIterator, BVG:902-935)
+        // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals
         if (parse && lane < k) {
             if (ic > 0) {
                 int64_t prev = 0;
@@ -244,8 +240,43 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
             }
             nres = (uint32_t)extra;
+        }
+        // ---- pool allocation: full list if some later node may copy it (referenced inside the row, or one of
+        //      the last W nodes of the row), otherwise only the residual values
+        uint64_t refmask = 0;
+        if (LEAN) for (uint32_t r = 1; r <= W && r < 64; r++) refmask |= ballot(parse && lane < k && ref == r) >> r;
+        uint32_t size = 0, sincl = 0;
+        bool stored = true;
+        for (;;) {
+            const uint32_t tailstart = k > W ? k - W : 0;
+            stored = !LEAN || lane >= tailstart || ((refmask >> lane) & 1ull);
+            size = (needed && lane < k) ? (stored ? dclamp : (nres > CAP ? CAP + 1 : nres)) : 0u;
+            sincl = wave_incl_scan32(size);
+            if (__shfl(sincl, (int)k - 1, 64) <= avail) break;
+            const uint32_t kf = (uint32_t)__popcll(ballot(sincl <= avail && lane < k));
+            if (kf == 0) { k = 0; break; }
+            k = kf;
+        }
+        if (k == 0) {                                                         // first node alone overflows the pool
+            failed = true;
+            { const uint32_t d0 = __shfl(d, 0, 64); fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64; }
+            break;
+        }
+        const bool act = needed && lane < k;
+        const uint32_t base = pool_used + (sincl - size);
+        if (act) nd_base[(uint32_t)x & RM] = base;
+        pool_used += __shfl(sincl, (int)k - 1, 64);
+        produced[lane] = act ? 0u : kInf;
+        // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
+        uint64_t nxt_off = 0, nxt_end = 0;
+        {
+            const int64_t nx = r0 + k + lane;
+            if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
+        }
+        // ---- D2: residuals (ResidualLongIterator, BVG:902-935) to the tail of the node's pool area
+        if (parse && lane < k) {
             if (nres > 0 && !bad && !(a.dbg & 2)) {
-                T* const tail = pool + base + d - nres;
+                T* const tail = pool + base + size - nres;
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
                     uint64_t val = 0; uint32_t len = 0;
@@ -298,7 +329,8 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
         T ivcur = 0; uint32_t ivrem = 0, ivi = 0;
         if (ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }
         uint32_t rsi = 0;
-        T rhead = nres ? out[d - nres] : sentinel<T>();
+        const T* const rtail = pool + base + size - nres;                      // residual values (tail of the area)
+        T rhead = nres ? rtail[0] : sentinel<T>();
         uint32_t j = 0;
         uint64_t chk = 0;
         for (;;) {
@@ -313,7 +345,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                 const T c = cneed ? cval : sentinel<T>();
                 const T iv = ivrem ? ivcur : sentinel<T>();
                 T m = c < iv ? c : iv; m = m < rhead ? m : rhead;             // MergedLongIterator.java:63-92, three-way
-                out[j] = m;
+                if (stored) out[j] = m;
                 j++;
                 __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (!MAT && rep) {
@@ -331,7 +363,7 @@ __global__ void __launch_bounds__(64) rows_kernel(DecodeArgs a) {
                     ivcur++;
                     if (--ivrem == 0 && ivi < ic) { ivcur = scr[ib + 2 * ivi]; ivrem = (uint32_t)scr[ib + 2 * ivi + 1]; ivi++; }
                 }
-                if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? out[d - nres + rsi] : sentinel<T>(); }
+                if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? rtail[rsi] : sentinel<T>(); }
             }
         }
         if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }
