@@ -88,8 +88,8 @@ def test_errors_map_to_reference_exceptions(W, small):
         g.decode_range(5, 4)
     with pytest.raises(W.UnsupportedOperationException):
         W.BVGraph.from_memory(W.default_params(nodes=1, outdegree_coding=W.ZETA), b"\x80", np.array([0, 1], dtype=np.uint64))   # BVG:658
-    with pytest.raises(W.IllegalStateException):
-        W.BVGraph.from_memory(W.default_params(nodes=1), b"\x80", None)    # no offsets: BVGraph.java:832,1136
+    with pytest.raises(W.EOFException):
+        W.BVGraph.from_memory(W.default_params(nodes=3), b"\x80", None)    # offsets derived from the stream: it ends after 1 node
 
 
 def test_offsets_and_outdegrees_by_products(small):
@@ -237,3 +237,27 @@ def test_successors_batch_random_access(W, small, cnr_golden):
     deg, succ = c.successors_batch(nodes)
     assert np.array_equal(succ, np.concatenate([cnr_golden[x] for x in nodes]))
     assert deg.tolist() == [len(cnr_golden[x]) for x in nodes]
+
+
+def test_offsets_are_derived_when_absent(W, tools, oracle, tmp_path, cnr_csr):
+    """loadSequential / loadOffline need no .offsets (BVGraph.java:1345-1464); BVGraph -O (writeOffsets, :2595-2609):
+    the device derives the index from the stream; it must equal the encoder's / the fixture's offsets."""
+    g = W.BVGraph.from_memory(W.parse_properties(open(CNR + ".properties").read()), open(CNR + ".graph", "rb").read(), None)
+    assert np.array_equal(g.offsets(), oracle.Graph.load(CNR).offsets())
+    deg, succ = g.decode_range(0, 5000)
+    assert np.array_equal(deg, cnr_csr[0][:5000]) and np.array_equal(succ, cnr_csr[1][:int(cnr_csr[0][:5000].sum())])
+    for kw in (dict(), dict(window_size=0, max_ref_count=0, min_interval_length=0), dict(residual_coding=1, outdegree_coding=1, reference_coding=2, block_count_coding=5, block_coding=1),
+               dict(residual_coding=7), dict(zeta_k=5, min_interval_length=2)):
+        st = tools.synth_store(6000, seed=17, params=W.default_params(**kw), chunk_nodes=1024, threads=2)
+        h = W.BVGraph.from_memory(st.params, st.graph, None)
+        assert np.array_equal(h.offsets(), st.offsets), kw
+    base = str(tmp_path / "g")
+    st.write(base)
+    import os
+    os.remove(base + ".offsets")
+    with pytest.raises(W.IOException):
+        W.BVGraph.load(base)                                                # the standard load needs the file
+    q = W.BVGraph.load_sequential(base)
+    assert np.array_equal(q.offsets(), st.offsets)
+    q2 = W.BVGraph.load_offline(base)
+    assert q2.scan()["arcs"] == st.stats["arcs"]

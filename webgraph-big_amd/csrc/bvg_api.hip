@@ -521,7 +521,6 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
     if (!p || !out) return BVG_E_ARG;
     int r = check_params(*p); if (r) return r;
     r = ensure_device(device); if (r) return r;
-    if (!h_offsets && !d_offsets_in) return BVG_E_STATE;    // sequential-only graphs: offsets derivation is a later row
     Shared* sh = new Shared();
     sh->device = device; sh->p = *p; sh->nbytes = nbytes;
     sh->wide = p->nodes > (int64_t)0x7FFFFFFF;
@@ -539,7 +538,21 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
     else {
         HIPCHK(hipMalloc(&sh->d_offsets, ((size_t)n + 1) * sizeof(uint64_t)));
         sh->own_offsets = true;
-        HIPCHK(hipMemcpy(sh->d_offsets, h_offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (h_offsets) HIPCHK(hipMemcpy(sh->d_offsets, h_offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        else {
+            // no .offsets (loadSequential / loadOffline, BVG:1345-1464; BVGraph -O, BVG:2595-2609): derive the index from
+            // the stream itself with one sequential pass on the device
+            unsigned* d_err = nullptr;
+            HIPCHK(hipMalloc(&d_err, sizeof(unsigned)));
+            HIPCHK(hipMemset(d_err, 0, sizeof(unsigned)));
+            launch_derive_offsets(sh->d_graph, sh->padded, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), sh->d_offsets, d_err, nullptr);
+            unsigned herr = 0;
+            hipError_t e = hipMemcpy(&herr, d_err, sizeof(unsigned), hipMemcpyDeviceToHost);
+            (void)hipFree(d_err);
+            if (e != hipSuccess) { release_shared(sh); return BVG_E_HIP; }
+            if (getenv("BVG_DEBUG")) { uint64_t last = 0; (void)hipMemcpy(&last, sh->d_offsets + n, 8, hipMemcpyDeviceToHost); fprintf(stderr, "[bvg] derive offsets: err=%u end=%llu of %llu bits\n", herr, (unsigned long long)last, (unsigned long long)nbytes * 8); }
+            if (herr) { release_shared(sh); return (herr & ERR_REF_RANGE) ? BVG_E_STATE : BVG_E_EOF; }
+        }
     }
     HIPCHK(hipMemcpy(&sh->total_bits, sh->d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (sh->total_bits > nbytes * 8) { release_shared(sh); return BVG_E_EOF; }
@@ -653,9 +666,13 @@ int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out) {
     bvg_params p;
     r = bvg_parse_properties((const char*)props.data(), props.size(), &p); if (r) return r;
     r = read_file(base + ".graph", graph); if (r) return r;
-    // The index is needed by every GPU entry point; sequential/offline modes use it too when present.
+    // Standard / mapped loads read basename.offsets (BVG:1545-1558).  Sequential / offline loads (BVG:1345-1464) do not
+    // have to have it: the index is then derived from the stream on the device.
     r = read_file(base + ".offsets", offs);
-    if (r) return load_mode >= BVG_LOAD_STANDARD ? BVG_E_IO : BVG_E_STATE;
+    if (r) {
+        if (load_mode >= BVG_LOAD_STANDARD) return BVG_E_IO;
+        return open_common(&p, graph.data(), nullptr, graph.size(), nullptr, nullptr, device, out);
+    }
     std::vector<uint64_t> offsets((size_t)p.nodes + 1);
     r = bvg_decode_offsets(offs.data(), offs.size(), p.nodes, p.offset_coding, offsets.data()); if (r) return r;
     return open_common(&p, graph.data(), nullptr, graph.size(), offsets.data(), nullptr, device, out);

@@ -68,6 +68,11 @@ void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t*
 void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
                       int outdegree_coding, int window, uint32_t* maxd, hipStream_t s);
 
+// offsets index from a bare .graph (BVGraph -O / writeOffsets, BVG:2595-2609; loadSequential/loadOffline, BVG:1345-1464):
+// one wavefront parses the stream sequentially (all lanes in step, LDS-staged); offsets[n+1] out, err[0] != 0 on a bad stream
+void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod,
+                           uint64_t* offsets, unsigned* err, hipStream_t s);
+
 // synthetic tiling (bvg_tile)
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
 void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);
