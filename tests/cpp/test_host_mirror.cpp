@@ -46,6 +46,18 @@ int main(int argc, char** argv) {
             const int64_t* sa = it2.successorBigArray();
             for (size_t j = 0; j < ra.size(); j++) if (ra[j] != sa[j]) { printf("FAIL successor mismatch\n"); return 1; }
         }
+        {   // frontier-style batched random access
+            std::vector<int64_t> fr = {0, n - 1, n / 2, 5, 5, n / 3};
+            std::vector<int32_t> fd; std::vector<int64_t> fs;
+            g->successorsBatch(fr, fd, fs);
+            size_t o = 0;
+            for (size_t q = 0; q < fr.size(); q++) {
+                auto ra = g->successorBigArray(fr[q]);
+                if ((size_t)fd[q] != ra.size()) { printf("FAIL batch outdegree\n"); return 1; }
+                for (size_t j = 0; j < ra.size(); j++) if (fs[o + j] != ra[j]) { printf("FAIL batch successors\n"); return 1; }
+                o += ra.size();
+            }
+        }
         threw = false;
         try { g->outdegree(n); } catch (const std::invalid_argument&) { threw = true; }
         if (!threw) { printf("FAIL no IllegalArgumentException\n"); return 1; }

@@ -124,6 +124,15 @@ public:
         if (x < 0 || x >= p_.nodes) throw std::invalid_argument("Node index out of range");
         std::vector<int32_t> d; std::vector<int64_t> s; decodeRange(x, x + 1, d, s); return s;
     }
+    // successors(x) for a whole frontier (bvg_successors_batch): outdegrees + concatenated lists in request order
+    void successorsBatch(const std::vector<int64_t>& nodes, std::vector<int32_t>& deg, std::vector<int64_t>& succ) {
+        deg.resize(nodes.size());
+        uint64_t need = 0;
+        int st = bvg_successors_batch(h_, nodes.data(), (int64_t)nodes.size(), deg.data(), nullptr, 0, &need);
+        if (st != BVG_E_CAPACITY) check(st, "successors_batch");
+        succ.resize((size_t)need);
+        if (need) check(bvg_successors_batch(h_, nodes.data(), (int64_t)nodes.size(), deg.data(), succ.data(), need, &need), "successors_batch");
+    }
     NodeIterator nodeIterator(int64_t from = 0) { return NodeIterator(shared_from_this(), from, INT64_MAX); }   // BVGraph.java:1257
     std::vector<NodeIterator> splitNodeIterators(int howMany) {                            // ImmutableGraph.java:405-436
         std::vector<NodeIterator> v; const int64_t n = p_.nodes, m = (n + howMany - 1) / howMany;
