@@ -88,3 +88,43 @@ def test_synthetic_graphs_match_oracle(W, tools, oracle, params):
     assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc)
     r, o = g.scan(), og.scan()
     assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"])
+
+
+def test_randomised_parameters_and_shapes(W, tools, oracle):
+    """Randomised sweep: window / maxRef / minInterval / zeta_k / codings x graph shape, full materialise + scan
+    parity against the oracle (the reference's testCompression idea, BVGraphTest.java:52-103, at random)."""
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        kw = dict(window_size=int(rng.choice([0, 1, 2, 7, 16, 64])), max_ref_count=int(rng.choice([0, 1, 3, 1000])),
+                  min_interval_length=int(rng.choice([0, 1, 2, 4, 9])), zeta_k=int(rng.choice([1, 2, 3, 4, 7])))
+        if rng.random() < 0.4:
+            kw.update(outdegree_coding=int(rng.choice([1, 2])), block_coding=int(rng.choice([1, 2, 5])), residual_coding=int(rng.choice([1, 2, 3, 6, 7])),
+                      reference_coding=int(rng.choice([1, 2, 5])), block_count_coding=int(rng.choice([1, 2, 5])))
+            if kw["residual_coding"] == 3:
+                kw["zeta_k"] = int(rng.choice([1, 3, 5, 8]))
+        n = int(rng.choice([1, 2, 63, 64, 65, 500, 3000]))
+        synth = tools.web_like(mean_deg=float(rng.choice([2, 10, 60])), p_copy=float(rng.choice([0.0, 0.5, 0.95])), p_empty=float(rng.choice([0.0, 0.3, 0.9])),
+                               p_interval=float(rng.choice([0.0, 0.5])), max_deg=int(rng.choice([5, 300, 5000])), window=int(rng.choice([1, 7, 30])))
+        st = tools.synth_store(n, seed=int(rng.integers(1 << 30)), params=W.default_params(**kw), synth=synth, chunk_nodes=int(rng.choice([64, 1 << 16])), threads=2)
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+        og = _oracle_graph(oracle, st)
+        deg, succ = g.decode_range(0, n)
+        odeg, osucc = og.decode_range(0, n)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), (trial, kw, n)
+        r, o = g.scan(), og.scan()
+        assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), (trial, kw, n)
+        g.close()
+
+
+def test_degenerate_graphs(W, tools, oracle):
+    for lists in ([], [[]], [[0]], [[] for _ in range(200)], [list(range(0, 5000))], [[1], [0]], [list(range(64))] * 70):
+        st = tools.store(lists, W.default_params())
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+        deg, succ = g.decode_range(0, len(lists))
+        assert deg.tolist() == [len(l) for l in lists]
+        assert succ.tolist() == [v for l in lists for v in l]
+        r = g.scan()
+        assert r["arcs"] == sum(map(len, lists)) and r["nodes"] == len(lists)
+        if lists:
+            og = _oracle_graph(oracle, st)
+            assert r["chk"] == og.scan()["chk"]
