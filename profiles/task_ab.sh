@@ -1,0 +1,8 @@
+# A/B: level-synchronous task emission (BVG_DBG=8) against the pipelined node-per-lane loop
+run() { BVG_DBG=$3 timeout 300 python bench.py --shape $1 --steps 3 --warmup 1 --target-gib $2 --no-cpu-baseline 2>&1 | grep -E "^\{" | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); print('%.1f Gedges/s kernel %.1f ms slow %d'%(d['value']/1e9, d['roofline']['kernel_ms'], d.get('slow_blocks',-1)))"; }
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+BVG_DBG=8 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for sh in eu web w0; do for m in 0 8; do echo "$sh dbg=$m : $(run $sh 1 $m)"; done; done

@@ -67,7 +67,7 @@ struct bvg_graph {
     Shared* sh = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    unsigned long long* d_acc = nullptr;      // 4 words
+    unsigned long long* d_acc = nullptr;      // 4 result words + 8 debug counters
     uint32_t* d_fail = nullptr;               // [0] count, [1..] list
     uint32_t fail_cap = 0;
     uint64_t node_base = 0;
@@ -151,7 +151,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
     }
     HIPCHK(hipEventCreate(&g->ev0));
     HIPCHK(hipEventCreate(&g->ev1));
-    HIPCHK(hipMalloc(&g->d_acc, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g->d_acc, 12 * sizeof(unsigned long long)));
     g->fail_cap = 1u << 16;
     HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     *out = g;
@@ -271,7 +271,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         g->fail_cap = nblocks;
         HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     }
-    HIPCHK(hipMemsetAsync(g->d_acc, 0, 4 * sizeof(unsigned long long), g->stream));
+    HIPCHK(hipMemsetAsync(g->d_acc, 0, 12 * sizeof(unsigned long long), g->stream));
     HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
 
     DecodeArgs a{};
@@ -335,7 +335,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (getenv("BVG_POOL")) cap = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)cap; a.lds_scr_elems = 0;
         } else {
-            uint64_t pool = ((uint64_t)(avg * 48.0) + 255) & ~255ull;   // ~a row of lists (rows shrink when they do not fit)
+            const bool task = (a.dbg & 8u) != 0;                          // task emission parks the row's residuals beside the lists
+            uint64_t pool = ((uint64_t)(avg * (task ? 60.0 : 48.0)) + 255) & ~255ull;   // ~a row of lists (rows shrink when they do not fit)
             pool = std::min<uint64_t>(std::max<uint64_t>(pool, 1024), wide ? 4096 : 8192);
             if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
@@ -503,8 +504,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     }
     if (d_work) (void)hipFree(d_work);
 
-    unsigned long long acc[4];
+    unsigned long long acc[12];
     HIPCHK(hipMemcpy(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost));
+    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: merge steps %llu, task passes %llu (with seeks %llu), rows %llu, tasks %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7]);
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;

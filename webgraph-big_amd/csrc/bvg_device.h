@@ -170,24 +170,41 @@ __host__ __device__ __forceinline__ uint64_t mix_keyed(uint32_t k0, uint32_t k1,
 // ---- wave64 helpers ----
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
-// inclusive prefix sum over the 64 lanes of a wavefront
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if ((int)lane_id() >= o) v += t;
-    }
+// Cross-lane data movement with DPP (no LDS traffic): lanes without a source, or masked off, read 0.
+template <int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+constexpr int kRowShr = 0x110, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+// value of lane `idx` (wave-uniform idx) broadcast through an SGPR
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t idx) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)idx));
+}
+__device__ __forceinline__ uint64_t lane_get64(uint64_t v, uint32_t idx) {
+    return ((uint64_t)lane_get((uint32_t)(v >> 32), idx) << 32) | lane_get((uint32_t)v, idx);
+}
+// inclusive prefix sum over the 64 lanes of a wavefront: 4 rows of 16 lanes scanned with row_shr, then
+// stitched with the two row broadcasts
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    uint32_t v = x + dpp0<kRowShr + 1, 0xf, 0xf>(x) + dpp0<kRowShr + 2, 0xf, 0xf>(x) + dpp0<kRowShr + 3, 0xf, 0xf>(x);
+    v += dpp0<kRowShr + 4, 0xf, 0xe>(v);
+    v += dpp0<kRowShr + 8, 0xf, 0xc>(v);
+    v += dpp0<kRowBcast15, 0xa, 0xf>(v);
+    v += dpp0<kRowBcast31, 0xc, 0xf>(v);
     return v;
 }
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v) { return lane_get(wave_incl_scan(v), 63); }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
-    return v;
+__device__ __forceinline__ uint32_t wave_or32(uint32_t x) {
+    uint32_t v = x | dpp0<kRowShr + 1, 0xf, 0xf>(x) | dpp0<kRowShr + 2, 0xf, 0xf>(x) | dpp0<kRowShr + 3, 0xf, 0xf>(x);
+    v |= dpp0<kRowShr + 4, 0xf, 0xe>(v);
+    v |= dpp0<kRowShr + 8, 0xf, 0xc>(v);
+    v |= dpp0<kRowBcast15, 0xa, 0xf>(v);
+    v |= dpp0<kRowBcast31, 0xc, 0xf>(v);
+    return lane_get(v, 63);
 }
 
 }  // namespace bvg

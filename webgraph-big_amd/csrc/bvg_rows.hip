@@ -25,6 +25,9 @@
 #ifndef BVG_ROWS_WAVES
 #define BVG_ROWS_WAVES 6
 #endif
+#ifndef BVG_TASK_WAVES
+#define BVG_TASK_WAVES 4
+#endif
 
 namespace bvg {
 
@@ -33,20 +36,21 @@ namespace {
 constexpr uint32_t kInf = 0xFFFFFFFFu;
 constexpr uint32_t LIN = 0xFFFFFFFFu;          // linear window: no index mask
 constexpr uint32_t RM = kRing - 1;
+constexpr uint32_t kMinTask = 4;               // shortest task (outputs) worth a seek
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
-__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint32_t t = __shfl_up(v, o, 64);
-        if ((int)lane_id() >= o) v += t;
-    }
-    return v;
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) { return wave_incl_scan(v); }
+
+// lower bound in a sorted LDS array: number of elements < v
+template <typename T> __device__ __forceinline__ uint32_t lds_lower_bound(const T* arr, uint32_t n, T v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (arr[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
 }
 
-template <typename T, bool MAT, bool GEN>
-__global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) {
+template <typename T, bool MAT, bool GEN, bool TASK>
+__global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint32_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
@@ -82,6 +86,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
     unsigned err = 0;
     bool failed = false;
     uint32_t fail_need = 0xFFFFFFFFu;                        // pool elements that would have been enough (when known)
+    uint32_t cnt_iter = 0, cnt_pass = 0, cnt_rows = 0, cnt_tasks = 0, cnt_seek = 0;   // BVG_DBG & 64: work counters (wave-uniform)
 
     int64_t r0 = hs;
     // offsets of the first row (later rows are prefetched while the previous row is decoded)
@@ -96,8 +101,8 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
         const uint32_t left = (uint32_t)(e - r0 > 64 ? 64 : e - r0);
         {   // (re)stage the window when this row's records are not covered by it
-            const uint64_t row_lo = __shfl(off_x, 0, 64);
-            const uint64_t row_hi = __shfl(rec_end, (int)left - 1, 64);
+            const uint64_t row_lo = lane_get64(off_x, 0);
+            const uint64_t row_hi = lane_get64(rec_end, left - 1);
             if (!(row_lo >= stg_bit0 && row_hi + 96 <= stg_bit0 + stg_bits)) {
                 __syncthreads();
                 const uint64_t b0 = (row_lo >> 3) & ~15ull;
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         const uint32_t dclamp = d > CAP ? CAP + 1 : d;
         const uint32_t incl = wave_incl_scan32(dclamp);
         uint32_t avail = CAP - pool_used;
-        const uint32_t total = __shfl(incl, 63, 64);
+        const uint32_t total = lane_get(incl, 63);
         if (total > avail && pool_used > 0) {
             // compact: keep only the lists of the last W nodes, moved to the front of the pool
             uint32_t my_d = 0, my_base = 0; const int64_t y = r0 - (int64_t)W + (int64_t)lane;
@@ -144,12 +149,12 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
             const uint32_t nincl = wave_incl_scan32(my_d);
             const uint32_t nbase = nincl - my_d;
             for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
-                const uint32_t src = __shfl(my_base, (int)jn, 64), dst = __shfl(nbase, (int)jn, 64), len = __shfl(my_d, (int)jn, 64);
+                const uint32_t src = lane_get(my_base, jn), dst = lane_get(nbase, jn), len = lane_get(my_d, jn);
                 if (src != dst)
                     for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
             }
             if (livelane) nd_base[(uint32_t)y & RM] = nbase;
-            pool_used = __shfl(nincl, 63, 64);
+            pool_used = lane_get(nincl, 63);
             avail = CAP - pool_used;
             __syncthreads();
         }
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         // Steps A..D with two wave-uniform points where the scratch area (copy blocks, then intervals) is
         // allocated by prefix sums; lanes whose entries do not fit are cut from the row (k shrinks) and
         // their nodes are simply parsed again at the head of the next row.
-        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
+        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0, di = 0;
         int64_t extra = d;
         const bool parse = needed && lane < k && d > 0 && !(a.dbg & 4);
         // ---- A: reference and block count (BVG:1015-1021)
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCR)); k = kb < k ? kb : k; }
         if (k == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }        // one node's copy blocks exceed the scratch area
         sb = bincl - bc;
-        const uint32_t btot = __shfl(bincl, (int)k - 1, 64);
+        const uint32_t btot = lane_get(bincl, k - 1);
         // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
         if (parse && lane < k) {
             if (ref > 0) {
@@ -234,7 +239,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
                     const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
                     const int64_t len = (int64_t)v2 + minint;
                     prev = leftv + len;
-                    extra -= len;
+                    extra -= len; di += (uint32_t)len;
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
                 if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
@@ -245,28 +250,45 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         //      the last W nodes of the row), otherwise only the residual values
         uint64_t refmask = 0;
         if (LEAN) for (uint32_t r = 1; r <= W && r < 64; r++) refmask |= ballot(parse && lane < k && ref == r) >> r;
-        uint32_t size = 0, sincl = 0;
+        uint32_t size = 0, sincl = 0, rtb = 0;
         bool stored = true;
         for (;;) {
             const uint32_t tailstart = k > W ? k - W : 0;
             stored = !LEAN || lane >= tailstart || ((refmask >> lane) & 1ull);
-            size = (needed && lane < k) ? (stored ? dclamp : (nres > CAP ? CAP + 1 : nres)) : 0u;
-            sincl = wave_incl_scan32(size);
-            if (__shfl(sincl, (int)k - 1, 64) <= avail) break;
-            const uint32_t kf = (uint32_t)__popcll(ballot(sincl <= avail && lane < k));
+            uint32_t tot;
+            if (TASK) {
+                // lists grow from the bottom of the pool; the row's residual values are parked top-down and die
+                // with the row (tasks of one node run concurrently, so they cannot share the list's own tail)
+                size = (needed && lane < k && stored) ? dclamp : 0u;
+                const uint32_t rsz = (needed && lane < k) ? (nres > CAP ? CAP + 1 : nres) : 0u;
+                sincl = wave_incl_scan32(size);
+                const uint32_t rincl = wave_incl_scan32(rsz);
+                rtb = CAP - (rincl > CAP ? CAP : rincl);
+                tot = sincl + rincl;
+            } else {
+                size = (needed && lane < k) ? (stored ? dclamp : (nres > CAP ? CAP + 1 : nres)) : 0u;
+                sincl = wave_incl_scan32(size);
+                tot = sincl;
+            }
+            if (lane_get(tot, k - 1) <= avail) break;
+            const uint32_t kf = (uint32_t)__popcll(ballot(tot <= avail && lane < k));
             if (kf == 0) { k = 0; break; }
             k = kf;
         }
         if (k == 0) {                                                         // first node alone overflows the pool
             failed = true;
-            { const uint32_t d0 = __shfl(d, 0, 64); fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64; }
+            {
+                uint32_t d0 = lane_get(d, 0); const uint32_t n0 = lane_get(nres, 0);
+                if (TASK && d0 <= 0x3FFFFFFFu) d0 += n0 > d0 ? d0 : n0;
+                fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64;
+            }
             break;
         }
         const bool act = needed && lane < k;
         const uint32_t base = pool_used + (sincl - size);
         if (act) nd_base[(uint32_t)x & RM] = base;
-        pool_used += __shfl(sincl, (int)k - 1, 64);
-        produced[lane] = act ? 0u : kInf;
+        pool_used += lane_get(sincl, k - 1);
+        if (!TASK) produced[lane] = act ? 0u : kInf;
         // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
         uint64_t nxt_off = 0, nxt_end = 0;
         {
@@ -276,7 +298,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         // ---- D2: residuals (ResidualLongIterator, BVG:902-935) to the tail of the node's pool area
         if (parse && lane < k) {
             if (nres > 0 && !bad && !(a.dbg & 2)) {
-                T* const tail = pool + base + size - nres;
+                T* const tail = TASK ? pool + rtb : pool + base + size - nres;
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
                     uint64_t val = 0; uint32_t len = 0;
@@ -302,7 +324,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
                     if (rel > pend) { err |= ERR_OVERRUN; break; }
                 }
             }
-            if (rel != pend && !bad && !a.dbg) err |= ERR_MALFORMED;         // SURVEY A.6 self-check
+            if (rel != pend && !bad && !(a.dbg & 7u)) err |= ERR_MALFORMED;         // SURVEY A.6 self-check
         } else if (act && d == 0 && rel != pend && !bad) err |= ERR_MALFORMED;
         if (ballot(bad && lane < k)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
         __syncthreads();
@@ -311,62 +333,216 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         const bool rep = act && x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
         if (rep && !MAT) { const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k0 = (uint32_t)kx; k1 = (uint32_t)(kx >> 32) | 1u; }
-        T* const out = pool + base;
-        const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; uint32_t rlane = lane; bool samerow = false;
-        if (act && ref > 0) {
-            const int64_t y = x - ref;
-            rl = pool + nd_base[(uint32_t)y & RM]; rlen = nd_d[(uint32_t)y & RM];
-            if (y >= r0) { rlane = lane - ref; samerow = true; }
-            if (bc == 0) keep = kInf;                                         // MaskedLongIterator.java:73-78
-            else {
-                keep = (uint32_t)scr[sb]; bi = 1;
-                if (keep == 0) {
-                    if (bi >= bc) rpos = rlen;
-                    else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
+        if constexpr (TASK) {
+            // Level-synchronous emission by TASKS.  Nodes are grouped by their depth in the row's reference forest;
+            // within a level every node is cut into tasks of ~S outputs (value ranges delimited by splitters taken
+            // from its longest stream) and the tasks, not the nodes, are dealt to the lanes, so a row costs about
+            // (successors in the row)/64 merge steps per level instead of its longest list.  A task seeks the three
+            // streams to its first splitter (block walk for the mask, lower bounds for list/residuals) and then runs
+            // the same three-way merge (MergedLongIterator.java:63-92) until the next splitter.
+            uint32_t* const tmap = produced;
+            uint32_t rlbN = 0, rlenN = 0;
+            if (act && ref > 0) { const int64_t y = x - ref; rlbN = nd_base[(uint32_t)y & RM]; rlenN = nd_d[(uint32_t)y & RM]; }
+            const uint32_t rtbN = rtb;
+            const bool inrow = act && ref > 0 && ref <= lane;
+            uint32_t lvl = 0;
+            for (int it = 0; it < 64; it++) {
+                const uint32_t up = __shfl(lvl, inrow ? (int)(lane - ref) : (int)lane, 64);
+                const uint32_t nl = inrow ? up + 1 : 0;
+                const bool ch = nl != lvl; lvl = nl;
+                if (!ballot(ch)) break;
+            }
+            const bool emitn = act && d > 0 && !(a.dbg & 1);
+            uint32_t axis = 0, la = rlenN;                                    // the longest stream gives the splitters
+            if (nres > la) { la = nres; axis = 1; }
+            if (di > la) { la = di; axis = 2; }
+            uint32_t emitted = 0;
+            uint64_t remaining = ballot(emitn);
+            for (uint32_t L = 0; remaining; L++) {
+                const bool mem = emitn && lvl == L;
+                remaining &= ~ballot(mem);
+                const uint32_t Wl = wave_sum32(mem ? d : 0u);
+                // S: (about) the smallest task length for which the level's tasks fit the 64 lanes in one pass
+                uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
+                for (int it = 0; it < 4; it++) {
+                    uint32_t tn = 0;
+                    if (mem) { tn = (uint32_t)((float)d / (float)S); if (tn * S < d) tn++; }
+                    const uint32_t tt = wave_sum32(tn);
+                    if (tt <= 64u) break;
+                    const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
+                    S = s2 > S ? s2 : S + 1u;
+                }
+                uint32_t Tn = 0, step = 1;
+                if (mem) {
+                    step = (uint32_t)((float)S * (float)la / (float)d); if (step < 1u) step = 1u;
+                    Tn = (uint32_t)((float)la / (float)step);
+                    while (Tn * step < la) Tn++;
+                    while (Tn > 1u && (Tn - 1u) * step >= la) Tn--;
+                    if (Tn == 0) Tn = 1;
+                }
+                const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+                for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+                    {   // task map of this pass: (node lane, task index inside the node)
+                        const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
+                        const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
+                        for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
+                    }
+                    __syncthreads();
+                    const bool tl = p0 + lane < Ttot;
+                    const uint32_t ent = tl ? tmap[lane] : lane;
+                    const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                    const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64);
+                    const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
+                    const uint32_t t_nres = __shfl(nres, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
+                    const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1) | (axis << 2), nl, 64);
+                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64), t_step = __shfl(step, nl, 64), t_la = __shfl(la, nl, 64);
+                    const bool t_stored = t_fl & 1u, t_rep = (t_fl >> 1) & 1u; const uint32_t t_axis = t_fl >> 2;
+                    const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
+                    uint32_t rpos = 0, keep = kInf, bi = 0, j = 0, j0 = 0, rsi = 0, ivrem = 0, ivi = t_ic;
+                    T ivcur = 0, rhead = sentinel<T>(), vend = sentinel<T>();
+                    bool run = tl;
+                    if (tl) {
+                        if (t_bc > 0) {                                       // MaskedLongIterator.java:73-78
+                            keep = (uint32_t)scr[t_sb]; bi = 1;
+                            if (keep == 0) {
+                                if (bi >= t_bc) rpos = t_rlen;
+                                else { rpos += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; } }
+                            }
+                        }
+                        const uint32_t lo = q * t_step, hi = lo + t_step;    // splitter positions on the axis stream
+                        T vstart = 0;
+                        if (t_axis == 0) { if (hi < t_la) vend = rl[hi]; if (q) vstart = rl[lo]; }
+                        else if (t_axis == 1) { if (hi < t_la) vend = rt[hi]; if (q) vstart = rt[lo]; }
+                        else {
+                            uint32_t acc = 0;
+                            for (uint32_t i = 0; i < t_ic; i++) {
+                                const T left = scr[t_ib + 2 * i]; const uint32_t len = (uint32_t)scr[t_ib + 2 * i + 1];
+                                if (q && lo >= acc && lo < acc + len) vstart = left + (T)(lo - acc);
+                                if (hi >= acc && hi < acc + len) vend = left + (T)(hi - acc);
+                                acc += len;
+                            }
+                        }
+                        uint32_t kept = 0, cnti = 0;
+                        if (q) {                                              // seek the mask to the first list position >= vstart
+                            const uint32_t p = t_axis == 0 ? lo : lds_lower_bound(rl, t_rlen, vstart);
+                            for (;;) {
+                                if (rpos >= p) break;
+                                if (keep == kInf || rpos + keep > p) { kept += p - rpos; if (keep != kInf) keep -= p - rpos; rpos = p; break; }
+                                kept += keep; rpos += keep;
+                                if (bi >= t_bc) { rpos = t_rlen; break; }
+                                rpos += (uint32_t)scr[t_sb + bi]; bi++;
+                                if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; }
+                            }
+                            rsi = t_axis == 1 ? lo : lds_lower_bound(rt, t_nres, vstart);
+                        }
+                        for (uint32_t i = 0; i < t_ic; i++) {                 // seek the intervals
+                            const T left = scr[t_ib + 2 * i]; const uint32_t len = (uint32_t)scr[t_ib + 2 * i + 1];
+                            if ((T)(left + len) > vstart) {
+                                const uint32_t off = vstart > left ? (uint32_t)(vstart - left) : 0u;
+                                cnti += off; ivcur = left + (T)off; ivrem = len - off; ivi = i + 1;
+                                break;
+                            }
+                            cnti += len;
+                        }
+                        j0 = kept + cnti + rsi; j = j0;
+                        if (rsi < t_nres) rhead = rt[rsi];
+                    }
+                    cnt_pass++; cnt_tasks += (uint32_t)__popcll(ballot(tl)); cnt_seek += ballot(tl && q) ? 1u : 0u;
+                    for (;;) {
+                        if (!ballot(run)) break;
+                        cnt_iter++;
+                        if (run) {
+                            const bool cneed = rpos < t_rlen;
+                            const T c = cneed ? rl[rpos] : sentinel<T>();
+                            const T iv = ivrem ? ivcur : sentinel<T>();
+                            T m = c < iv ? c : iv; m = m < rhead ? m : rhead;
+                            if (m >= vend || j >= t_d) run = false;           // the next task (or nothing) starts here
+                            else {
+                                if (t_stored) out[j] = m;
+                                j++;
+                                if (!MAT && t_rep) blk_chk += mix_keyed(t_k0, t_k1, (uint64_t)m + a.node_base);
+                                if (cneed && c == m) {                        // MaskedLongIterator.java:81-100
+                                    rpos++;
+                                    if (--keep == 0) {
+                                        if (bi >= t_bc) rpos = t_rlen;
+                                        else { rpos += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; } }
+                                    }
+                                }
+                                if (ivrem && iv == m) {                       // LongIntervalSequenceIterator.java:71-78
+                                    ivcur++;
+                                    if (--ivrem == 0 && ivi < t_ic) { ivcur = scr[t_ib + 2 * ivi]; ivrem = (uint32_t)scr[t_ib + 2 * ivi + 1]; ivi++; }
+                                }
+                                if (rsi < t_nres && rhead == m) { rsi++; rhead = rsi < t_nres ? rt[rsi] : sentinel<T>(); }
+                            }
+                        }
+                    }
+                    emitted += j - j0;
+                    __syncthreads();
                 }
             }
-        }
-        T ivcur = 0; uint32_t ivrem = 0, ivi = 0;
-        if (ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }
-        uint32_t rsi = 0;
-        const T* const rtail = pool + base + size - nres;                      // residual values (tail of the area)
-        T rhead = nres ? rtail[0] : sentinel<T>();
-        uint32_t j = 0;
-        uint64_t chk = 0;
-        for (;;) {
-            const bool todo = act && j < d && !(a.dbg & 1);
-            if (!ballot(todo)) break;
-            const bool cneed = todo && rpos < rlen;
-            // both loads are issued together; the copy head is only used when the producer is far enough
-            const uint32_t pr = __hip_atomic_load(&produced[rlane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const T cval = rl[cneed ? rpos : 0];
-            const bool cready = !cneed || !samerow || pr > rpos;
-            if (todo && cready) {
-                const T c = cneed ? cval : sentinel<T>();
-                const T iv = ivrem ? ivcur : sentinel<T>();
-                T m = c < iv ? c : iv; m = m < rhead ? m : rhead;             // MergedLongIterator.java:63-92, three-way
-                if (stored) out[j] = m;
-                j++;
-                __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (!MAT && rep) {
-                    const uint64_t y64 = m == sentinel<T>() ? ~0ull : (uint64_t)m + a.node_base;
-                    chk += mix_keyed(k0, k1, y64);
-                }
-                if (cneed && c == m) {                                        // MaskedLongIterator.java:81-100
-                    rpos++;
-                    if (--keep == 0) {
+            // every list must come out with exactly d entries; anything else (duplicates across the streams, a
+            // malformed record) is left to the generic kernel, which follows the reference's iterators literally
+            if (wave_sum32(emitted) != wave_sum32(emitn ? d : 0u)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
+            if (rep) { blk_arcs += d; blk_nodes += 1; }
+        } else {
+            T* const out = pool + base;
+            const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; uint32_t rlane = lane; bool samerow = false;
+            if (act && ref > 0) {
+                const int64_t y = x - ref;
+                rl = pool + nd_base[(uint32_t)y & RM]; rlen = nd_d[(uint32_t)y & RM];
+                if (y >= r0) { rlane = lane - ref; samerow = true; }
+                if (bc == 0) keep = kInf;                                         // MaskedLongIterator.java:73-78
+                else {
+                    keep = (uint32_t)scr[sb]; bi = 1;
+                    if (keep == 0) {
                         if (bi >= bc) rpos = rlen;
                         else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
                     }
                 }
-                if (ivrem && iv == m) {                                       // LongIntervalSequenceIterator.java:71-78
-                    ivcur++;
-                    if (--ivrem == 0 && ivi < ic) { ivcur = scr[ib + 2 * ivi]; ivrem = (uint32_t)scr[ib + 2 * ivi + 1]; ivi++; }
-                }
-                if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? rtail[rsi] : sentinel<T>(); }
             }
+            T ivcur = 0; uint32_t ivrem = 0, ivi = 0;
+            if (ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }
+            uint32_t rsi = 0;
+            const T* const rtail = pool + base + size - nres;                      // residual values (tail of the area)
+            T rhead = nres ? rtail[0] : sentinel<T>();
+            uint32_t j = 0;
+            uint64_t chk = 0;
+            for (;;) {
+                const bool todo = act && j < d && !(a.dbg & 1);
+                if (!ballot(todo)) break;
+                cnt_iter++;
+                const bool cneed = todo && rpos < rlen;
+                // both loads are issued together; the copy head is only used when the producer is far enough
+                const uint32_t pr = __hip_atomic_load(&produced[rlane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const T cval = rl[cneed ? rpos : 0];
+                const bool cready = !cneed || !samerow || pr > rpos;
+                if (todo && cready) {
+                    const T c = cneed ? cval : sentinel<T>();
+                    const T iv = ivrem ? ivcur : sentinel<T>();
+                    T m = c < iv ? c : iv; m = m < rhead ? m : rhead;             // MergedLongIterator.java:63-92, three-way
+                    if (stored) out[j] = m;
+                    j++;
+                    __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (!MAT && rep) {
+                        const uint64_t y64 = m == sentinel<T>() ? ~0ull : (uint64_t)m + a.node_base;
+                        chk += mix_keyed(k0, k1, y64);
+                    }
+                    if (cneed && c == m) {                                        // MaskedLongIterator.java:81-100
+                        rpos++;
+                        if (--keep == 0) {
+                            if (bi >= bc) rpos = rlen;
+                            else { rpos += (uint32_t)scr[sb + bi]; bi++; if (bi >= bc) keep = kInf; else { keep = (uint32_t)scr[sb + bi]; bi++; } }
+                        }
+                    }
+                    if (ivrem && iv == m) {                                       // LongIntervalSequenceIterator.java:71-78
+                        ivcur++;
+                        if (--ivrem == 0 && ivi < ic) { ivcur = scr[ib + 2 * ivi]; ivrem = (uint32_t)scr[ib + 2 * ivi + 1]; ivi++; }
+                    }
+                    if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? rtail[rsi] : sentinel<T>(); }
+                }
+            }
+            if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }
         }
-        if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }
 
         // ------------------------------------------------------------------ materialise: coalesced copy-out
         if (MAT) {
@@ -375,8 +551,8 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
             if (repmask) {
                 const int la = __ffsll((unsigned long long)repmask) - 1;
                 const int lb = 63 - __clzll(repmask);
-                const uint32_t seg0 = __shfl(base, la, 64);
-                const uint32_t seg1 = __shfl(base + d, lb, 64);
+                const uint32_t seg0 = lane_get(base, (uint32_t)la);
+                const uint32_t seg1 = lane_get(base + d, (uint32_t)lb);
                 const uint64_t dst0 = a.batch ? a.cum[bid >> 1] : a.cum[(r0 + la) - a.from];
                 for (uint32_t t = lane; t < seg1 - seg0; t += 64) {
                     const T vv = pool[seg0 + t];
@@ -387,6 +563,7 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         }
         __syncthreads();
         // next row: lanes shift by k; reuse the prefetched offsets
+        cnt_rows++;
         r0 += k;
         off_x = nxt_off; rec_end = nxt_end;
     }
@@ -405,6 +582,10 @@ __global__ void __launch_bounds__(64, BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) 
         atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
         atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
         if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+        if (a.dbg & 64u) {
+            atomicAdd(&a.acc[4], (unsigned long long)cnt_iter); atomicAdd(&a.acc[5], (unsigned long long)cnt_pass); atomicAdd(&a.acc[6], (unsigned long long)cnt_rows);
+            atomicAdd(&a.acc[7], (unsigned long long)cnt_tasks); atomicAdd(&a.acc[8], (unsigned long long)cnt_seek);
+        }
     }
 }
 
@@ -416,8 +597,11 @@ void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
     const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (size_t)a.lds_stage_words * 4;
-#define BVG_RL(T, M) do { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true>), grid, block, dyn, s, a); \
-                          else hipLaunchKernelGGL((rows_kernel<T, M, false>), grid, block, dyn, s, a); } while (0)
+    const bool task = (a.dbg & 8u) != 0;
+#define BVG_RL(T, M) do { if (task) { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, true>), grid, block, dyn, s, a); \
+                                      else hipLaunchKernelGGL((rows_kernel<T, M, false, true>), grid, block, dyn, s, a); } \
+                          else { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, false>), grid, block, dyn, s, a); \
+                                 else hipLaunchKernelGGL((rows_kernel<T, M, false, false>), grid, block, dyn, s, a); } } while (0)
     if (!wide) { if (!materialise) BVG_RL(uint32_t, false); else BVG_RL(uint32_t, true); }
     else { if (!materialise) BVG_RL(uint64_t, false); else BVG_RL(uint64_t, true); }
 #undef BVG_RL
