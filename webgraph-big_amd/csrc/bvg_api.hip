@@ -42,7 +42,18 @@ struct Plan {
     std::vector<uint64_t> h_first;
     std::vector<uint32_t> h_maxd;             // largest (list + the W lists before it) a block decodes: predicts its tier
     uint64_t version = 0;
+    // residual skip index (built by two passes of the row kernel the first time a large range is decoded)
+    int skip_state = 0;                       // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index)
+    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint32_t* d_skip_bit = nullptr; uint64_t* d_skip_val = nullptr;
+    std::vector<uint64_t> h_skip_first;
+    void release_skip() {
+        if (d_skip_first) (void)hipFree(d_skip_first);
+        if (d_skip_bit) (void)hipFree(d_skip_bit);
+        if (d_skip_val) (void)hipFree(d_skip_val);
+        d_skip_first = nullptr; d_skip_bit = nullptr; d_skip_val = nullptr; skip_total = 0; skip_state = 0; h_skip_first.clear();
+    }
     void release() {
+        release_skip();
         if (d_first) (void)hipFree(d_first);
         if (d_halo) (void)hipFree(d_halo);
         if (d_mask) (void)hipFree(d_mask);
@@ -57,7 +68,7 @@ struct Shared {
     uint64_t* d_offsets = nullptr; bool own_offsets = false;
     uint64_t total_bits = 0;
     bool wide = false;
-    Plan plan; std::mutex mu;
+    Plan plan; std::mutex mu; std::mutex skip_mu;
     std::atomic<int> refs{1};
 };
 
@@ -76,6 +87,7 @@ struct bvg_graph {
     // predicted tiers run concurrently with tier 0 on high-priority side streams (their few, long blocks are the critical path)
     hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t side_ev[2] = {nullptr, nullptr};
     void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
+    int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     struct Pred { uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0; } pred;
 };
 
@@ -248,10 +260,55 @@ uint32_t block_bits_of(const bvg_graph* g) { return g->tun.block_bits ? g->tun.b
 struct BatchPlan { const uint64_t* d_first; const uint32_t* d_halo; const uint64_t* d_mask; uint32_t requests; };
 
 int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
-               bvg_scan_result* res, const BatchPlan* batch = nullptr) {
+               bvg_scan_result* res, const BatchPlan* batch = nullptr);
+
+// Residual skip index: nodes with long residual lists get one entry per kSkipEvery residuals, so the row kernel can decode a
+// long list as independent segments on otherwise idle lanes.  Two passes of the ordinary decode over the whole graph: count the
+// entries of every block, prefix-sum on the host, fill.  An index, not a cache: every gap is still decoded from the stream.
+int build_skip(bvg_graph* g) {
+    Shared* sh = g->sh;
+    std::lock_guard<std::mutex> lk(sh->skip_mu);
+    Plan& pl = sh->plan;
+    if (pl.skip_state) return 0;
+    const uint32_t nblk = pl.nblk;
+    const int64_t n = sh->p.nodes;
+    if (!nblk || n == 0) { pl.skip_state = 1; return 0; }
+    uint32_t* d_cnt = nullptr;
+    HIPCHK(hipMalloc(&d_cnt, (size_t)nblk * sizeof(uint32_t)));
+    HIPCHK(hipMemset(d_cnt, 0, (size_t)nblk * sizeof(uint32_t)));
+    g->skip_mode = 1; g->skip_cnt = d_cnt;
+    int r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr);
+    g->skip_mode = 0; g->skip_cnt = nullptr;
+    std::vector<uint32_t> cnt(nblk);
+    if (!r && hipMemcpy(cnt.data(), d_cnt, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
+    (void)hipFree(d_cnt);
+    if (r) { pl.skip_state = 1; return 0; }                // a bad stream surfaces in the caller's own decode; no index then
+    std::vector<uint64_t> first(nblk + 1, 0);
+    for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + cnt[i];
+    const uint64_t total = first[nblk];
+    if (total == 0) { pl.skip_state = 1; return 0; }
+    if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&pl.d_skip_val, total * sizeof(uint64_t)) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; (void)hipGetLastError(); return 0; }
+    if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; return 0; }
+    pl.skip_total = total;
+    g->skip_mode = 2;
+    r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr);
+    g->skip_mode = 0;
+    if (r) { pl.release_skip(); pl.skip_state = 1; return 0; }
+    pl.h_skip_first.swap(first);
+    pl.skip_state = 1;
+    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * 12.0 / 1048576.0);
+    return 0;
+}
+
+int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
+               bvg_scan_result* res, const BatchPlan* batch) {
     Shared* sh = g->sh;
     int r = 0;
     if (!batch) { r = build_plan(g, block_bits_of(g)); if (r) return r; }
+    const bool rows_default = (g->tun.reserved & 0xFF) == 0 && !g->tun.force_slow;
+    if (!batch && rows_default && g->skip_mode == 0 && !sh->plan.skip_state && !getenv("BVG_NOSKIP") &&
+        (to - from) >= sh->p.nodes / 4 && (to - from) >= 4096) { r = build_skip(g); if (r) return r; }
     const Plan& pl = sh->plan;
     const bool wide = sh->wide || g->tun.force_wide;
     // block range
@@ -283,6 +340,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
     a.dbg = getenv("BVG_DBG") ? (uint32_t)strtoul(getenv("BVG_DBG"), nullptr, 10) : 0;
+    a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
+    if (!batch && rows_default && pl.skip_total && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state)) {
+        a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val;
+    }
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
     const bool legacy = (g->tun.reserved & 0xFF) == 1;     // A/B switch: the generic row kernel (BitCursor) in LDS as tier 0/1
     a.grab_threshold = (g->tun.reserved >> 8) ? (g->tun.reserved >> 8) : 40;
@@ -511,6 +572,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;
         res->index_bytes = (uint64_t)(to - from + 1) * 8 + (uint64_t)nblocks * 20;
+        if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * 12 + (uint64_t)nblocks * 8;
         res->graph_bytes = 0;
     }
     if (acc[3] & ERR_REF_RANGE) return BVG_E_STATE;

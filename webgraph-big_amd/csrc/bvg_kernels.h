@@ -8,6 +8,7 @@
 namespace bvg {
 
 // LDS geometry of the fast (one wavefront per node block) decode kernel.
+constexpr uint32_t kSkipMin = 48, kSkipEvery = 32;   // residual skip index granularity
 constexpr int kRing = 128;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
 constexpr int kMaxWindow = 64;       // larger windows take the slow path only if a block needs it; beyond: unsupported
 constexpr int kMaxHalo = 64;         // halo nodes a block may need from before its first node (one row)
@@ -41,6 +42,13 @@ struct DecodeArgs {
     uint32_t grab_threshold;            // stream kernel: idle lanes that trigger a batched grab
     uint32_t batch;                     // 1 = bvg_successors_batch: block 2i is request i; outputs are indexed by request
     uint32_t dbg;                       // timing experiments only (BVG_DBG): 1 skip emission, 2 skip residual decode, 4 skip parse
+    // residual skip index (row kernel): for every node with >= kSkipMin residuals, one entry per kSkipEvery residuals
+    // {bit offset of that residual's code from the record start, value of the residual before it}; entries of a block
+    // are contiguous, in node order.  skip_mode 1 = count entries per block, 2 = fill them, 0 = use them when present.
+    const uint64_t* skip_first;         // nblk+1 entry indices, or nullptr
+    uint32_t* skip_bit; void* skip_val; // entries (skip_val: 8 bytes per entry whatever the successor type)
+    uint32_t* skip_cnt;                 // skip_mode 1: per-block entry count out
+    uint32_t skip_mode;
 };
 
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);

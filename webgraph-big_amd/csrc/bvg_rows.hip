@@ -49,11 +49,34 @@ template <typename T> __device__ __forceinline__ uint32_t lds_lower_bound(const 
     return lo;
 }
 
+// one residual gap at bit `rel` of the staged window (BVG:788-795): zeta_k from a 32-bit window when it fits, else the
+// 64-bit decoders; returns the code length, 0 = does not fit 64 bits (fail over)
+template <bool GEN> __device__ __forceinline__ uint32_t read_residual(const uint32_t* stage, uint32_t rel, bool zfast, uint32_t zk, int coding, uint64_t& val) {
+    uint32_t len = 0; val = 0;
+    if (zfast) {
+        const uint32_t w = win32<LIN>(stage, rel);
+        const uint32_t z = w ? (uint32_t)__builtin_clz(w) : 32u;
+        const uint32_t nbz = z * zk + zk - 1, zt = z + 1 + nbz;
+        if (zt < 32) {
+            const uint32_t tt = (w << (z + 1)) >> (32u - nbz);
+            const uint32_t leftv = 1u << (z * zk);
+            if (tt < leftv) { val = tt + leftv - 1u; len = zt; }
+            else { val = ((tt << 1) | ((w >> (31u - zt)) & 1u)) - 1u; len = zt + 1; }
+        }
+    }
+    if (len == 0) {
+        const uint64_t w = win64<LIN>(stage, rel);
+        len = GEN ? decode_generic_w(w, coding, zk, &val) : zeta64(w, zk, val);
+    }
+    return len;
+}
+
 template <typename T, bool MAT, bool GEN, bool TASK>
 __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint32_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
+    __shared__ uint32_t rtmap[64];                // residual segments -> lanes (skip index)
     __shared__ uint32_t produced[64];             // read/written with wavefront-scope relaxed atomics: plain ds_read/ds_write that
                                                   // the compiler may not cache (a `volatile` here compiles to flat sc0 sc1 + vmcnt(0))
 
@@ -87,6 +110,13 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     bool failed = false;
     uint32_t fail_need = 0xFFFFFFFFu;                        // pool elements that would have been enough (when known)
     uint32_t cnt_iter = 0, cnt_pass = 0, cnt_rows = 0, cnt_tasks = 0, cnt_seek = 0;   // BVG_DBG & 64: work counters (wave-uniform)
+
+    // residual skip index: entries of this block (sk_n > 0: use them; skip_mode 1/2: count / fill)
+    const bool sk_have = a.skip_first != nullptr && !a.batch;
+    const uint64_t sk_base = sk_have ? a.skip_first[bid] : 0ull;
+    const uint32_t sk_n = sk_have ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
+    const bool sk_track = a.skip_mode != 0 || sk_n != 0;
+    uint32_t sk_run = 0;
 
     int64_t r0 = hs;
     // offsets of the first row (later rows are prefetched while the previous row is decoded)
@@ -295,29 +325,73 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             const int64_t nx = r0 + k + lane;
             if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
         }
-        // ---- D2: residuals (ResidualLongIterator, BVG:902-935) to the tail of the node's pool area
-        if (parse && lane < k) {
+        // ---- D2: residuals (ResidualLongIterator, BVG:902-935) to the node's parking area in the pool
+        const uint32_t recrel = (uint32_t)(off_x - stg_bit0);
+        uint32_t cntE = 0, efirst = 0;
+        if (sk_track) {                                                       // skip entries of the row, in node order
+            cntE = (parse && lane < k && !bad && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
+            const uint32_t eincl = wave_incl_scan32(cntE);
+            efirst = sk_run + eincl - cntE;
+            sk_run += lane_get(eincl, 63);
+        }
+        const uint32_t rdst = TASK ? rtb : base + size - nres;
+        if (a.skip_mode == 0 && sk_n != 0 && ballot(cntE != 0) && !(a.dbg & 2)) {
+            // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task
+            if (sk_run > sk_n) { failed = true; fail_need = 0xFFFFFFF5u; break; }      // index out of step with the stream
+            const uint32_t Tn = (parse && lane < k && nres > 0 && !bad) ? 1u + cntE : 0u;
+            const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+            bool tbad = false;
+            for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+                {
+                    const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
+                    const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
+                    for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
+                }
+                __syncthreads();
+                const bool tl = p0 + lane < Ttot;
+                const uint32_t ent = tl ? rtmap[lane] : lane;
+                const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
+                const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(rdst, nl, 64), t_ef = __shfl(efirst, nl, 64);
+                if (tl) {
+                    const uint32_t t0 = q * kSkipEvery;
+                    const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
+                    const uint32_t cnt = q == t_ce ? t_nres - t0 : kSkipEvery;            // the last segment takes the remainder
+                    uint32_t trel = t_rel; T r = (T)(r0 + nl);
+                    if (q) {
+                        const uint64_t e = sk_base + t_ef + q - 1u;
+                        trel = t_rec + a.skip_bit[e]; r = (T)reinterpret_cast<const uint64_t*>(a.skip_val)[e];
+                        if (!(trel > t_rel && trel < t_pend)) tbad = true;
+                    }
+                    T* const tail = pool + t_dst + t0;
+                    for (uint32_t i = 0; i < cnt && !tbad; i++) {
+                        uint64_t val;
+                        const uint32_t len = read_residual<GEN>(stage, trel, zfast, zk, a.cod.residual, val);
+                        if (len == 0) { tbad = true; break; }
+                        trel += len;
+                        r = (t0 + i) == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
+                        tail[i] = r;
+                        if (trel > t_pend) { err |= ERR_OVERRUN; break; }
+                    }
+                    if (t0 + cnt == t_nres && trel != t_pend && !tbad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
+                }
+                __syncthreads();
+            }
+            if (((act && d == 0) || (parse && lane < k && nres == 0)) && rel != pend && !bad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
+            bad |= tbad;
+            if (ballot(tbad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
+        } else if (parse && lane < k) {
             if (nres > 0 && !bad && !(a.dbg & 2)) {
-                T* const tail = TASK ? pool + rtb : pool + base + size - nres;
+                T* const tail = pool + rdst;
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
-                    uint64_t val = 0; uint32_t len = 0;
-                    if (zfast) {                                              // zeta_k from a 32-bit window
-                        const uint32_t w = win32<LIN>(stage, rel);
-                        const uint32_t z = w ? (uint32_t)__builtin_clz(w) : 32u;
-                        const uint32_t nbz = z * zk + zk - 1, zt = z + 1 + nbz;
-                        if (zt < 32) {
-                            const uint32_t tt = (w << (z + 1)) >> (32u - nbz);
-                            const uint32_t leftv = 1u << (z * zk);
-                            if (tt < leftv) { val = tt + leftv - 1u; len = zt; }
-                            else { val = ((tt << 1) | ((w >> (31u - zt)) & 1u)) - 1u; len = zt + 1; }
-                        }
+                    if (a.skip_mode == 2 && cntE && t && (t & (kSkipEvery - 1u)) == 0) {  // fill the skip entry of this residual
+                        const uint64_t e = sk_base + efirst + (t / kSkipEvery) - 1u;
+                        a.skip_bit[e] = rel - recrel; reinterpret_cast<uint64_t*>(a.skip_val)[e] = (uint64_t)r;
                     }
-                    if (len == 0) {                                           // long code / other coding: 64-bit window
-                        const uint64_t w = win64<LIN>(stage, rel);
-                        len = GEN ? decode_generic_w(w, a.cod.residual, zk, &val) : zeta64(w, zk, val);
-                        if (len == 0) { bad = true; break; }
-                    }
+                    uint64_t val;
+                    const uint32_t len = read_residual<GEN>(stage, rel, zfast, zk, a.cod.residual, val);
+                    if (len == 0) { bad = true; break; }
                     rel += len;
                     r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
                     tail[t] = r;
@@ -578,6 +652,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     }
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
+        if (a.skip_mode == 1 && a.skip_cnt) a.skip_cnt[bid] = sk_run;
         atomicAdd(&a.acc[0], (unsigned long long)blk_arcs);
         atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
         atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
