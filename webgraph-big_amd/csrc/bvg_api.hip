@@ -575,6 +575,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * 12 + (uint64_t)nblocks * 8;
         res->graph_bytes = 0;
     }
+    if (acc[3] && getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] error bits 0x%llx\n", acc[3]);
     if (acc[3] & ERR_REF_RANGE) return BVG_E_STATE;
     if (acc[3] & (ERR_OVERRUN | ERR_MALFORMED)) return BVG_E_EOF;
     return 0;

@@ -386,8 +386,10 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
                     if (a.skip_mode == 2 && cntE && t && (t & (kSkipEvery - 1u)) == 0) {  // fill the skip entry of this residual
-                        const uint64_t e = sk_base + efirst + (t / kSkipEvery) - 1u;
-                        a.skip_bit[e] = rel - recrel; reinterpret_cast<uint64_t*>(a.skip_val)[e] = (uint64_t)r;
+                        const uint32_t ei = efirst + (t / kSkipEvery) - 1u;                // inside the block's allotment only: a block
+                        if (ei < sk_n) {                                                    // that ends in the generic kernel has none
+                            a.skip_bit[sk_base + ei] = rel - recrel; reinterpret_cast<uint64_t*>(a.skip_val)[sk_base + ei] = (uint64_t)r;
+                        }
                     }
                     uint64_t val;
                     const uint32_t len = read_residual<GEN>(stage, rel, zfast, zk, a.cod.residual, val);
