@@ -1,0 +1,7 @@
+# BVG_EMIT=1: row kernel with per-row choice between task emission and the pipelined loop; 0: pipelined loop only
+run() { BVG_EMIT=$3 timeout 600 python bench.py --shape $1 --steps 3 --warmup 1 --target-gib $2 --no-cpu-baseline 2>&1 | grep -E "^\{|Error|error" | python -c "
+import sys,json
+for l in sys.stdin:
+    if not l.startswith('{'): print(l.strip()[:150]); continue
+    d=json.loads(l); print('%.1f Gedges/s kernel %.1f ms slow %d'%(d['value']/1e9, d['roofline']['kernel_ms'], d.get('slow_blocks',-1)))"; }
+for sh in ${SHAPES:-eu web w0}; do for m in ${MODES:-0 1}; do echo "$sh emit=$m: $(run $sh ${GIB:-2} $m)"; done; done

@@ -340,6 +340,13 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
     a.dbg = getenv("BVG_DBG") ? (uint32_t)strtoul(getenv("BVG_DBG"), nullptr, 10) : 0;
+    // Row-kernel variant: splitting lists into tasks pays on dense or reference-free graphs; sparse graphs with reference
+    // chains (several short levels per row) are served better by the pipelined node-per-lane loop alone.
+    {
+        const double avg_d = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
+        a.emit_tasks = (sh->p.window_size == 0 || avg_d >= 24.0) ? 1u : 0u;
+        if (getenv("BVG_EMIT")) a.emit_tasks = (uint32_t)strtoul(getenv("BVG_EMIT"), nullptr, 10) ? 1u : 0u;
+    }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
     if (!batch && rows_default && pl.skip_total && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state)) {
         a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val;
@@ -396,9 +403,16 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (getenv("BVG_POOL")) cap = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)cap; a.lds_scr_elems = 0;
         } else {
-            const bool task = (a.dbg & 8u) != 0;                          // task emission parks the row's residuals beside the lists
-            uint64_t pool = ((uint64_t)(avg * (task ? 60.0 : 48.0)) + 255) & ~255ull;   // ~a row of lists (rows shrink when they do not fit)
+            const bool task = a.emit_tasks != 0;                          // task emission parks the row's residuals beside the lists
+            uint64_t pool = ((uint64_t)(avg * (task ? 52.0 : 48.0)) + 255) & ~255ull;   // ~a row of lists (rows shrink when they do not fit)
             pool = std::min<uint64_t>(std::max<uint64_t>(pool, 1024), wide ? 4096 : 8192);
+            if (task) {
+                // resident waves per CU step down with the LDS footprint: take every byte of the step the pool lands on
+                const uint64_t lds_cu = 160 * 1024, fixed = (uint64_t)a.lds_stage_words * 4 + 1536 + 256;   // window + static arrays (+ slack)
+                auto foot = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed + 1023) & ~1023ull; };
+                const uint64_t waves = std::max<uint64_t>(1, lds_cu / foot(pool));
+                while (pool + 64 <= (wide ? 4096u : 8192u) && lds_cu / foot(pool + 64) == waves) pool += 64;
+            }
             if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
         }

@@ -193,6 +193,14 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
     return v;
 }
 __device__ __forceinline__ uint32_t wave_sum32(uint32_t v) { return lane_get(wave_incl_scan(v), 63); }
+__device__ __forceinline__ uint32_t wave_max32(uint32_t x) {
+    uint32_t v = max(max(x, dpp0<kRowShr + 1, 0xf, 0xf>(x)), max(dpp0<kRowShr + 2, 0xf, 0xf>(x), dpp0<kRowShr + 3, 0xf, 0xf>(x)));
+    v = max(v, dpp0<kRowShr + 4, 0xf, 0xe>(v));
+    v = max(v, dpp0<kRowShr + 8, 0xf, 0xc>(v));
+    v = max(v, dpp0<kRowBcast15, 0xa, 0xf>(v));
+    v = max(v, dpp0<kRowBcast31, 0xc, 0xf>(v));
+    return lane_get(v, 63);
+}
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -26,7 +26,7 @@
 #define BVG_ROWS_WAVES 6
 #endif
 #ifndef BVG_TASK_WAVES
-#define BVG_TASK_WAVES 4
+#define BVG_TASK_WAVES 5
 #endif
 
 namespace bvg {
@@ -37,6 +37,7 @@ constexpr uint32_t kInf = 0xFFFFFFFFu;
 constexpr uint32_t LIN = 0xFFFFFFFFu;          // linear window: no index mask
 constexpr uint32_t RM = kRing - 1;
 constexpr uint32_t kMinTask = 4;               // shortest task (outputs) worth a seek
+constexpr uint32_t kPassCost = 14;             // fixed cost of one level pass of the task emission, in merge steps
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
@@ -318,7 +319,6 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const uint32_t base = pool_used + (sincl - size);
         if (act) nd_base[(uint32_t)x & RM] = base;
         pool_used += lane_get(sincl, k - 1);
-        if (!TASK) produced[lane] = act ? 0u : kInf;
         // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
         uint64_t nxt_off = 0, nxt_end = 0;
         {
@@ -409,6 +409,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const bool rep = act && x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
         if (rep && !MAT) { const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k0 = (uint32_t)kx; k1 = (uint32_t)(kx >> 32) | 1u; }
+        bool by_tasks = false;
         if constexpr (TASK) {
             // Level-synchronous emission by TASKS.  Nodes are grouped by their depth in the row's reference forest;
             // within a level every node is cut into tasks of ~S outputs (value ranges delimited by splitters taken
@@ -432,8 +433,16 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             uint32_t axis = 0, la = rlenN;                                    // the longest stream gives the splitters
             if (nres > la) { la = nres; axis = 1; }
             if (di > la) { la = di; axis = 2; }
+            // Tasks pay a fixed cost per level (seeks, task map); the pipelined node-per-lane loop below costs about the
+            // longest list of the row.  Estimate both and take the cheaper one for this row.
+            const uint32_t rowW = wave_sum32(emitn ? d : 0u);
+            {
+                const uint32_t maxd = wave_max32(emitn ? d : 0u), nlev = wave_max32(emitn ? lvl + 1u : 0u);
+                const uint32_t est = ((rowW * 21u) >> 10) + nlev * kPassCost;
+                by_tasks = (est < maxd || (a.dbg & 16u)) && !(a.dbg & 32u);
+            }
             uint32_t emitted = 0;
-            uint64_t remaining = ballot(emitn);
+            uint64_t remaining = by_tasks ? ballot(emitn) : 0ull;
             for (uint32_t L = 0; remaining; L++) {
                 const bool mem = emitn && lvl == L;
                 remaining &= ~ballot(mem);
@@ -558,9 +567,14 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             }
             // every list must come out with exactly d entries; anything else (duplicates across the streams, a
             // malformed record) is left to the generic kernel, which follows the reference's iterators literally
-            if (wave_sum32(emitted) != wave_sum32(emitn ? d : 0u)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
-            if (rep) { blk_arcs += d; blk_nodes += 1; }
-        } else {
+            if (by_tasks) {
+                if (wave_sum32(emitted) != rowW) { failed = true; fail_need = 0xFFFFFFF5u; break; }
+                if (rep) { blk_arcs += d; blk_nodes += 1; }
+            }
+        }
+        if (!by_tasks) {
+            produced[lane] = act ? 0u : kInf;
+            __syncthreads();
             T* const out = pool + base;
             const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; uint32_t rlane = lane; bool samerow = false;
             if (act && ref > 0) {
@@ -579,7 +593,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             T ivcur = 0; uint32_t ivrem = 0, ivi = 0;
             if (ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }
             uint32_t rsi = 0;
-            const T* const rtail = pool + base + size - nres;                      // residual values (tail of the area)
+            const T* const rtail = pool + rdst;                                    // the node's residual values
             T rhead = nres ? rtail[0] : sentinel<T>();
             uint32_t j = 0;
             uint64_t chk = 0;
@@ -674,7 +688,7 @@ void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
     const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (size_t)a.lds_stage_words * 4;
-    const bool task = (a.dbg & 8u) != 0;
+    const bool task = a.emit_tasks != 0;
 #define BVG_RL(T, M) do { if (task) { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, true>), grid, block, dyn, s, a); \
                                       else hipLaunchKernelGGL((rows_kernel<T, M, false, true>), grid, block, dyn, s, a); } \
                           else { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, false>), grid, block, dyn, s, a); \
