@@ -72,6 +72,24 @@ template <bool GEN> __device__ __forceinline__ uint32_t read_residual(const uint
     return len;
 }
 
+// checksum term of successor m of a node whose key is (kA, k1), kA = k0 + lo(node_base) + hi(node_base) * 0x9E3779B1: the
+// same value as mix_keyed(k0, k1, m + node_base) with the 64-bit add folded into the key (a carry adds the constant once)
+template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t kA, uint32_t k1, T m, uint32_t nbl, bool nbz) {
+    if (sizeof(T) == 8) {
+        const uint64_t m64 = (uint64_t)m; const uint32_t ml = (uint32_t)m64, mh = (uint32_t)(m64 >> 32);
+        uint32_t a_ = ml + kA + mh * 0x9E3779B1u;
+        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
+        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
+        return (uint64_t)b * (uint64_t)k1;
+    } else {
+        const uint32_t ml = (uint32_t)m;
+        uint32_t a_ = ml + kA;
+        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
+        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
+        return (uint64_t)b * (uint64_t)k1;
+    }
+}
+
 template <typename T, bool MAT, bool GEN, bool TASK>
 __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
@@ -99,6 +117,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = !GEN && zk >= 2;
+    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
+    const bool nbz = a.node_base == 0;
     constexpr bool LEAN = !MAT;                              // scan mode: unreferenced lists are not materialised
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
@@ -408,7 +428,10 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         // ------------------------------------------------------------------ phase 2: data-flow emission
         const bool rep = act && x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
-        if (rep && !MAT) { const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k0 = (uint32_t)kx; k1 = (uint32_t)(kx >> 32) | 1u; }
+        if (rep && !MAT) {
+            const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
+            k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;                   // key with the node_base shift folded in (mix_node)
+        }
         bool by_tasks = false;
         if constexpr (TASK) {
             // Level-synchronous emission by TASKS.  Nodes are grouped by their depth in the row's reference forest;
@@ -448,7 +471,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 remaining &= ~ballot(mem);
                 const uint32_t Wl = wave_sum32(mem ? d : 0u);
                 // S: (about) the smallest task length for which the level's tasks fit the 64 lanes in one pass
-                uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
+                uint32_t S = (Wl * 5u + 255u) >> 8; if (S < kMinTask) S = kMinTask;    // start a little above W/64: one probe usually
                 for (int it = 0; it < 4; it++) {
                     uint32_t tn = 0;
                     if (mem) { tn = (uint32_t)((float)d / (float)S); if (tn * S < d) tn++; }
@@ -545,7 +568,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             else {
                                 if (t_stored) out[j] = m;
                                 j++;
-                                if (!MAT && t_rep) blk_chk += mix_keyed(t_k0, t_k1, (uint64_t)m + a.node_base);
+                                if (!MAT && t_rep) blk_chk += mix_node<T>(t_k0, t_k1, m, nb_lo, nbz);
                                 if (cneed && c == m) {                        // MaskedLongIterator.java:81-100
                                     rpos++;
                                     if (--keep == 0) {
@@ -613,10 +636,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (stored) out[j] = m;
                     j++;
                     __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    if (!MAT && rep) {
-                        const uint64_t y64 = m == sentinel<T>() ? ~0ull : (uint64_t)m + a.node_base;
-                        chk += mix_keyed(k0, k1, y64);
-                    }
+                    if (!MAT && rep) chk += m == sentinel<T>() ? mix_keyed(k0 - nb_lo - nb_hi * 0x9E3779B1u, k1, ~0ull) : mix_node<T>(k0, k1, m, nb_lo, nbz);
                     if (cneed && c == m) {                                        // MaskedLongIterator.java:81-100
                         rpos++;
                         if (--keep == 0) {
