@@ -66,7 +66,7 @@ typedef struct bvg_scan_result {
     uint64_t arcs;         /* sum of outdegrees */
     uint64_t chk;          /* sum over arcs (x,y) of bvg_arc_mix(x + node_base, y + node_base) mod 2^64 */
     uint64_t graph_bytes;  /* ALGORITHMIC bytes: compressed .graph bytes covering the scanned node range */
-    uint64_t index_bytes;  /* device index bytes the kernels read on top (offsets + block plan) */
+    uint64_t index_bytes;  /* device index bytes the kernels read on top (offsets + block plan + residual skip entries) */
     double kernel_ms;      /* hipEvent time of the scan kernel(s) on the handle's stream */
     uint32_t launches;     /* kernel launches issued (1 + slow-path relaunches) */
     uint32_t slow_blocks;  /* node blocks that had to take the global-memory slow path */
@@ -124,7 +124,9 @@ int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg,
  * allowed; outdeg[count] and the successor lists concatenated in request order.  Each request is
  * decoded together with the few earlier nodes its reference chain reaches (the recursion of BVG:1084). */
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
-/* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum). */
+/* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum).
+ * The first scan / decode that covers >= 1/4 of the nodes also builds the residual skip index (two extra passes, once per
+ * graph, shared by bvg_copy() flyweights; 12 bytes per 32 residuals of lists with >= 48 residuals; BVG_NOSKIP=1 disables). */
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
  * IG:405-436; cf. algo/HyperBall.java:748-768): bounds[0..k], bounds[0]=0, bounds[k]=nodes. */
