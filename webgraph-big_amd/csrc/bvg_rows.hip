@@ -508,7 +508,6 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
                     uint32_t rpos = 0, keep = kInf, bi = 0, j = 0, j0 = 0, rsi = 0, ivrem = 0, ivi = t_ic;
                     T ivcur = 0, rhead = sentinel<T>(), vend = sentinel<T>();
-                    bool run = tl;
                     if (tl) {
                         if (t_bc > 0) {                                       // MaskedLongIterator.java:73-78
                             keep = (uint32_t)scr[t_sb]; bi = 1;
@@ -556,32 +555,33 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                         if (rsi < t_nres) rhead = rt[rsi];
                     }
                     cnt_pass++; cnt_tasks += (uint32_t)__popcll(ballot(tl)); cnt_seek += ballot(tl && q) ? 1u : 0u;
+                    // `vend` doubles as the task's state: 0 (nothing is below it) for idle lanes and finished tasks
+                    if (!tl || j >= t_d) vend = 0;
                     for (;;) {
-                        if (!ballot(run)) break;
+                        const bool cneed = rpos < t_rlen;
+                        const T c = cneed ? rl[rpos] : sentinel<T>();
+                        const T iv = ivrem ? ivcur : sentinel<T>();
+                        T m = c < iv ? c : iv; m = m < rhead ? m : rhead;         // MergedLongIterator.java:63-92, three-way
+                        const bool emit = m < vend;                               // at vend the next task (or nothing) starts
+                        if (!ballot(emit)) break;
                         cnt_iter++;
-                        if (run) {
-                            const bool cneed = rpos < t_rlen;
-                            const T c = cneed ? rl[rpos] : sentinel<T>();
-                            const T iv = ivrem ? ivcur : sentinel<T>();
-                            T m = c < iv ? c : iv; m = m < rhead ? m : rhead;
-                            if (m >= vend || j >= t_d) run = false;           // the next task (or nothing) starts here
-                            else {
-                                if (t_stored) out[j] = m;
-                                j++;
-                                if (!MAT && t_rep) blk_chk += mix_node<T>(t_k0, t_k1, m, nb_lo, nbz);
-                                if (cneed && c == m) {                        // MaskedLongIterator.java:81-100
-                                    rpos++;
-                                    if (--keep == 0) {
-                                        if (bi >= t_bc) rpos = t_rlen;
-                                        else { rpos += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; } }
-                                    }
+                        if (emit) {
+                            if (t_stored) out[j] = m;
+                            j++;
+                            if (j >= t_d) vend = 0;
+                            if (!MAT && t_rep) blk_chk += mix_node<T>(t_k0, t_k1, m, nb_lo, nbz);
+                            if (cneed && c == m) {                            // MaskedLongIterator.java:81-100
+                                rpos++;
+                                if (--keep == 0) {
+                                    if (bi >= t_bc) rpos = t_rlen;
+                                    else { rpos += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; } }
                                 }
-                                if (ivrem && iv == m) {                       // LongIntervalSequenceIterator.java:71-78
-                                    ivcur++;
-                                    if (--ivrem == 0 && ivi < t_ic) { ivcur = scr[t_ib + 2 * ivi]; ivrem = (uint32_t)scr[t_ib + 2 * ivi + 1]; ivi++; }
-                                }
-                                if (rsi < t_nres && rhead == m) { rsi++; rhead = rsi < t_nres ? rt[rsi] : sentinel<T>(); }
                             }
+                            if (ivrem && iv == m) {                           // LongIntervalSequenceIterator.java:71-78
+                                ivcur++;
+                                if (--ivrem == 0 && ivi < t_ic) { ivcur = scr[t_ib + 2 * ivi]; ivrem = (uint32_t)scr[t_ib + 2 * ivi + 1]; ivi++; }
+                            }
+                            if (rsi < t_nres && rhead == m) { rsi++; rhead = rsi < t_nres ? rt[rsi] : sentinel<T>(); }
                         }
                     }
                     emitted += j - j0;
