@@ -85,10 +85,14 @@ struct bvg_graph {
     bvg_tuning tun{};
     void* slow_ws = nullptr; uint64_t slow_ws_bytes = 0;   // tier-2 (global-memory) pools, kept between calls
     // predicted tiers run concurrently with tier 0 on high-priority side streams (their few, long blocks are the critical path)
-    hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t side_ev[2] = {nullptr, nullptr};
+    static constexpr int kSide = 5;            // [0] giants (global-memory kernel), [1..4] one per LDS size class
+    hipStream_t side[kSide] = {}; hipEvent_t side_ev[kSide] = {};
     void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
-    struct Pred { uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0; } pred;
+    struct Pred {
+        uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
+        std::vector<uint8_t> learned; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
+    } pred;
 };
 
 namespace {
@@ -156,7 +160,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
     {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < bvg_graph::kSide; i++) {
             HIPCHK(hipStreamCreateWithPriority(&g->side[i], hipStreamNonBlocking, greatest));
             HIPCHK(hipEventCreateWithFlags(&g->side_ev[i], hipEventDisableTiming));
         }
@@ -365,6 +369,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (getenv("BVG_STAGE")) a.lds_stage_words = (uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u;
 
     uint32_t launches = 0, slow_blocks = 0;
+    bool predicted_run = false;                        // cascade outcomes of a predicted run are remembered in g->pred
     double kernel_ms = 0;
     std::vector<uint32_t> work;
     uint32_t* d_work = nullptr;
@@ -428,7 +433,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
             bvg_graph::Pred& pd = g->pred;
             const uint32_t pool0 = a.lds_pool_elems;
-            if (pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || !pd.d_lists) {
+            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u);
+            const bool rekey = pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
+            if (rekey) { pd.learned.assign(nblocks, 0); pd.dirty = false; }
+            if (rekey || pd.dirty) {
                 std::vector<uint32_t> L[6];
                 uint64_t gneed = 0;
                 for (uint32_t i = 0; i < nblocks; i++) {
@@ -439,9 +447,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     if (long_record) c = 5;
                     else if (need <= pool0) c = 0;
                     else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
+                    if (pd.learned[i] > c) { c = pd.learned[i]; if (c == 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
                     if (c == 5 && need > gneed) gneed = need;
                     L[c].push_back(lo + i);
                 }
+                pd.dirty = false; pd.mode = pmode;
                 if (pd.d_lists) { (void)hipFree(pd.d_lists); pd.d_lists = nullptr; }
                 HIPCHK(hipMalloc(&pd.d_lists, (size_t)nblocks * sizeof(uint32_t)));
                 size_t off = 0;
@@ -464,8 +474,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 }
             }
             HIPCHK(hipEventRecord(g->ev0, g->stream));
-            HIPCHK(hipStreamWaitEvent(g->side[0], g->ev0, 0));
-            HIPCHK(hipStreamWaitEvent(g->side[1], g->ev0, 0));
+            for (int i = 0; i < bvg_graph::kSide; i++) HIPCHK(hipStreamWaitEvent(g->side[i], g->ev0, 0));
             size_t off = 0;
             DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
             off += pd.count[0];
@@ -475,7 +484,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
                 for (uint32_t o2 = 0; o2 < pd.count[5]; o2 += gbatch) {
                     ag.work_list = pd.d_lists + offc[5] + o2;
-                    launch_decode(ag, std::min<uint32_t>(gbatch, pd.count[5] - o2), wide, materialise, true, g->side[1]);
+                    launch_decode(ag, std::min<uint32_t>(gbatch, pd.count[5] - o2), wide, materialise, true, g->side[0]);
                     launches++;
                 }
             }
@@ -483,14 +492,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (!pd.count[c]) continue;
                 DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_rows_decode(ac, pd.count[c], wide, materialise, g->side[0]);
+                launch_rows_decode(ac, pd.count[c], wide, materialise, g->side[c]);   // own stream: the classes overlap each other
                 launches++;
             }
             if (pd.count[0]) { launch_rows_decode(a0, pd.count[0], wide, materialise, g->stream); launches++; }
-            HIPCHK(hipEventRecord(g->side_ev[0], g->side[0]));
-            HIPCHK(hipEventRecord(g->side_ev[1], g->side[1]));
-            HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[0], 0));
-            HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[1], 0));
+            for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
             HIPCHK(hipStreamSynchronize(g->stream));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
@@ -498,6 +504,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant blocks, %.3f ms\n",
                                              pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], ms);
             slow_blocks = nblocks - pd.count[0];
+            predicted_run = true;
             if (pd.count[5] && !gbatch) {                                      // could not get the giant workspace: leave them to the cascade
                 std::vector<uint32_t> gl(pd.count[5]);
                 HIPCHK(hipMemcpy(gl.data(), pd.d_lists + offc[5], gl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -541,8 +548,15 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             std::vector<uint32_t> again;
             r = fetch_failures(again); if (r) return r;
             rest.insert(rest.end(), again.begin(), again.end());
+            if (predicted_run) {                               // remember where the survivors of this class fit
+                bvg_graph::Pred& pd = g->pred;
+                std::sort(again.begin(), again.end());
+                for (uint32_t id : work)
+                    if (id >= lo && id - lo < pd.learned.size() && !std::binary_search(again.begin(), again.end(), id)) { pd.learned[id - lo] = (uint8_t)(c + 1); pd.dirty = true; }
+            }
         }
         work.swap(rest);
+        if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id >= lo && id - lo < pd.learned.size()) { pd.learned[id - lo] = 5; pd.dirty = true; } }
     }
     // ---- tier 2: global-memory pools (kept in the handle), grown until every remaining block fits
     uint64_t pool_elems = 1ull << 20;
@@ -787,7 +801,7 @@ void bvg_close(bvg_graph* g) {
     if (g->slow_ws) (void)hipFree(g->slow_ws);
     if (g->giant_ws) (void)hipFree(g->giant_ws);
     if (g->pred.d_lists) (void)hipFree(g->pred.d_lists);
-    for (int i = 0; i < 2; i++) { if (g->side[i]) { (void)hipStreamSynchronize(g->side[i]); (void)hipStreamDestroy(g->side[i]); } if (g->side_ev[i]) (void)hipEventDestroy(g->side_ev[i]); }
+    for (int i = 0; i < bvg_graph::kSide; i++) { if (g->side[i]) { (void)hipStreamSynchronize(g->side[i]); (void)hipStreamDestroy(g->side[i]); } if (g->side_ev[i]) (void)hipEventDestroy(g->side_ev[i]); }
     release_shared(g->sh);
     delete g;
 }
