@@ -8,7 +8,7 @@ import csv,sys
 try:
     rows=[r for r in csv.DictReader(open(sys.argv[1])) if 'rows_kernel' in r['Kernel_Name']]
     g=max(int(r['Grid_Size_X']) for r in rows)
-    big=[r for r in rows if int(r['Grid_Size_X'])==g]
+    big=[r for r in rows if int(r['Grid_Size_X'])>=0.9*g]
     d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6 for r in big]
     print('tier-0 dispatches %d, last %.1f ms (all: %s)' % (len(d), d[-1], ' '.join('%.0f'%x for x in d)))
 except Exception as e:

@@ -5,7 +5,7 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'rows_kernel' in r['Kern
 for r in rows:
     r['s'] = int(r['Start_Timestamp']); r['e'] = int(r['End_Timestamp']); r['g'] = int(r['Grid_Size_X'])
 g = max(r['g'] for r in rows if 'rows_kernel' in r['Kernel_Name'])
-t0 = [r for r in rows if r['g'] == g]
+t0 = [r for r in rows if r['g'] >= 0.9 * g and 'rows_kernel' in r['Kernel_Name']]
 last = t0[-1]
 for r in sorted(rows, key=lambda r: r['s']):
     if r['s'] > last['s'] - 2000000 and r['s'] < last['e'] + 100000000:

@@ -21,7 +21,7 @@ for s, e, g, rk in L:
         seg[-1][1] = max(seg[-1][1], e)
     else:
         seg.append([s, e])
-t0 = [s for s, e, g, rk in L if rk and g == gmax]
+t0 = [s for s, e, g, rk in L if rk and g >= 0.9 * gmax]
 # boundary of scan k: start of the union segment that contains its tier-0 dispatch
 def seg_start(t):
     return max(a for a, b in seg if a <= t)

@@ -75,7 +75,8 @@ def _check(status, what=""):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "libbvgraph_hip.so")
+    # BVG_HIP_LIB: an alternative build of the same library (e.g. lib/libbvgraph_hip_prof.so, `make prof`: cycle timers compiled in)
+    return os.environ.get("BVG_HIP_LIB") or os.path.join(_HERE, "lib", "libbvgraph_hip.so")
 
 
 def build(force=False):

@@ -167,7 +167,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
     }
     HIPCHK(hipEventCreate(&g->ev0));
     HIPCHK(hipEventCreate(&g->ev1));
-    HIPCHK(hipMalloc(&g->d_acc, 12 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g->d_acc, 20 * sizeof(unsigned long long)));
     g->fail_cap = 1u << 16;
     HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     *out = g;
@@ -332,7 +332,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         g->fail_cap = nblocks;
         HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     }
-    HIPCHK(hipMemsetAsync(g->d_acc, 0, 12 * sizeof(unsigned long long), g->stream));
+    HIPCHK(hipMemsetAsync(g->d_acc, 0, 20 * sizeof(unsigned long long), g->stream));
     HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
 
     DecodeArgs a{};
@@ -593,9 +593,13 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     }
     if (d_work) (void)hipFree(d_work);
 
-    unsigned long long acc[12];
+    unsigned long long acc[20];
     HIPCHK(hipMemcpy(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost));
     if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: merge steps %llu, task passes %llu (with seeks %llu), rows %llu, tasks %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7]);
+    if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
+        fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
+        fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6);
+    }
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;

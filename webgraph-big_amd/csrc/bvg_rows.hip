@@ -131,6 +131,17 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     bool failed = false;
     uint32_t fail_need = 0xFFFFFFFFu;                        // pool elements that would have been enough (when known)
     uint32_t cnt_iter = 0, cnt_pass = 0, cnt_rows = 0, cnt_tasks = 0, cnt_seek = 0;   // BVG_DBG & 64: work counters (wave-uniform)
+    // -DBVG_PROF builds only (`make prof`): wave-cycles per section {row prep, level prep, task set-up, seeks, merge loop,
+    // phase 1, row set-up, headers, pool sizing, residuals}, reported with BVG_DBG & 64.  Off by default: the accumulators cost
+    // registers.  Wave-cycles measure latency, not issue slots: sections that other resident waves overlap look larger than they cost.
+#ifdef BVG_PROF
+    uint32_t cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // a block lives well under 2^32 cycles
+#define BVG_T0() ((uint32_t)clock64())
+#define BVG_T1(i, t) do { cyc[i] += (uint32_t)clock64() - (t); } while (0)
+#else
+#define BVG_T0() 0u
+#define BVG_T1(i, t) do { (void)(t); } while (0)
+#endif
 
     // residual skip index: entries of this block (sk_n > 0: use them; skip_mode 1/2: count / fill)
     const bool sk_have = a.skip_first != nullptr && !a.batch;
@@ -146,6 +157,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
 
     while (r0 < e) {
         // ------------------------------------------------------------------ row set-up
+        const uint32_t tq5 = BVG_T0();
         const int64_t x = r0 + lane;
         const bool in_range = x < e;
         const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
@@ -220,6 +232,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         if (needed && lane < k) nd_d[(uint32_t)x & RM] = d;
         __syncthreads();
 
+        BVG_T1(6, tq5);
+        const uint32_t tq7 = BVG_T0();
         // ------------------------------------------------------------------ phase 1: parse own record
         // Steps A..D with two wave-uniform points where the scratch area (copy blocks, then intervals) is
         // allocated by prefix sums; lanes whose entries do not fit are cut from the row (k shrinks) and
@@ -297,6 +311,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             }
             nres = (uint32_t)extra;
         }
+        BVG_T1(7, tq7);
+        const uint32_t tq8 = BVG_T0();
         // ---- pool allocation: full list if some later node may copy it (referenced inside the row, or one of
         //      the last W nodes of the row), otherwise only the residual values
         uint64_t refmask = 0;
@@ -345,6 +361,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             const int64_t nx = r0 + k + lane;
             if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
         }
+        BVG_T1(8, tq8);
+        const uint32_t tq9 = BVG_T0();
         // ---- D2: residuals (ResidualLongIterator, BVG:902-935) to the node's parking area in the pool
         const uint32_t recrel = (uint32_t)(off_x - stg_bit0);
         uint32_t cntE = 0, efirst = 0;
@@ -432,6 +450,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
             k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;                   // key with the node_base shift folded in (mix_node)
         }
+        BVG_T1(9, tq9);
+        BVG_T1(5, tq5);
         bool by_tasks = false;
         if constexpr (TASK) {
             // Level-synchronous emission by TASKS.  Nodes are grouped by their depth in the row's reference forest;
@@ -441,6 +461,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             // streams to its first splitter (block walk for the mask, lower bounds for list/residuals) and then runs
             // the same three-way merge (MergedLongIterator.java:63-92) until the next splitter.
             uint32_t* const tmap = produced;
+            const uint32_t tq0 = BVG_T0();
             uint32_t rlbN = 0, rlenN = 0;
             if (act && ref > 0) { const int64_t y = x - ref; rlbN = nd_base[(uint32_t)y & RM]; rlenN = nd_d[(uint32_t)y & RM]; }
             const uint32_t rtbN = rtb;
@@ -466,7 +487,9 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             }
             uint32_t emitted = 0;
             uint64_t remaining = by_tasks ? ballot(emitn) : 0ull;
+            BVG_T1(0, tq0);
             for (uint32_t L = 0; remaining; L++) {
+                const uint32_t tq1 = BVG_T0();
                 const bool mem = emitn && lvl == L;
                 remaining &= ~ballot(mem);
                 const uint32_t Wl = wave_sum32(mem ? d : 0u);
@@ -489,7 +512,9 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (Tn == 0) Tn = 1;
                 }
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+                BVG_T1(1, tq1);
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+                    const uint32_t tq2 = BVG_T0();
                     {   // task map of this pass: (node lane, task index inside the node)
                         const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
                         const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
@@ -529,6 +554,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                                 acc += len;
                             }
                         }
+                        BVG_T1(2, tq2);
+                        const uint32_t tq3 = BVG_T0();
                         uint32_t kept = 0, cnti = 0;
                         if (q) {                                              // seek the mask to the first list position >= vstart
                             const uint32_t p = t_axis == 0 ? lo : lds_lower_bound(rl, t_rlen, vstart);
@@ -553,10 +580,12 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                         }
                         j0 = kept + cnti + rsi; j = j0;
                         if (rsi < t_nres) rhead = rt[rsi];
+                        BVG_T1(3, tq3);
                     }
+                    const uint32_t tq4 = BVG_T0();
                     cnt_pass++; cnt_tasks += (uint32_t)__popcll(ballot(tl)); cnt_seek += ballot(tl && q) ? 1u : 0u;
                     // `vend` doubles as the task's state: 0 (nothing is below it) for idle lanes and finished tasks
-                    if (!tl || j >= t_d) vend = 0;
+                    if (!tl || j >= t_d || (a.dbg & 128u)) vend = 0;
                     for (;;) {
                         const bool cneed = rpos < t_rlen;
                         const T c = cneed ? rl[rpos] : sentinel<T>();
@@ -586,12 +615,13 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     }
                     emitted += j - j0;
                     __syncthreads();
+                    BVG_T1(4, tq4);
                 }
             }
             // every list must come out with exactly d entries; anything else (duplicates across the streams, a
             // malformed record) is left to the generic kernel, which follows the reference's iterators literally
             if (by_tasks) {
-                if (wave_sum32(emitted) != rowW) { failed = true; fail_need = 0xFFFFFFF5u; break; }
+                if (wave_sum32(emitted) != rowW && !(a.dbg & 128u)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
                 if (rep) { blk_arcs += d; blk_nodes += 1; }
             }
         }
@@ -696,6 +726,9 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         if (a.dbg & 64u) {
             atomicAdd(&a.acc[4], (unsigned long long)cnt_iter); atomicAdd(&a.acc[5], (unsigned long long)cnt_pass); atomicAdd(&a.acc[6], (unsigned long long)cnt_rows);
             atomicAdd(&a.acc[7], (unsigned long long)cnt_tasks); atomicAdd(&a.acc[8], (unsigned long long)cnt_seek);
+#ifdef BVG_PROF
+            for (int i = 0; i < 10; i++) atomicAdd(&a.acc[9 + i], (unsigned long long)cyc[i]);
+#endif
         }
     }
 }
