@@ -13,15 +13,21 @@ shutil.copy(newest(O + "/stats/*/*_kernel_stats.csv"), "profiles/%s_eu8g_kernel_
 out = {}
 for d in ("pmc_fetch", "pmc_valu", "pmc_misc"):
     rows = list(csv.DictReader(open(newest("%s/%s/*/*_counter_collection.csv" % (O, d)))))
+    rows = [r for r in rows if "rows_kernel" in r["Kernel_Name"] or "decode_kernel" in r["Kernel_Name"]]
+    # only the LAST scan of the run (steady state: skip index built, tiers learned): everything dispatched after the
+    # second-to-last tier-0 launch (tier 0 = the rows_kernel dispatches within 10 % of the largest grid)
+    gmax = max(int(r["Grid_Size"]) for r in rows if "rows_kernel" in r["Kernel_Name"])
+    big = sorted({int(r["Dispatch_Id"]) for r in rows if "rows_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 0.9 * gmax})
+    cut = big[-2] if len(big) > 1 else -1
+    rows = [r for r in rows if int(r["Dispatch_Id"]) > cut]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
         kn = r["Kernel_Name"]
-        if "rows_kernel" in kn or "decode_kernel" in kn:
-            name = ("rows_kernel" if "rows_kernel" in kn else "decode_kernel<slow>") + " lds=%s grid=%s" % (r["LDS_Block_Size"], r["Grid_Size"])
-            agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        name = ("rows_kernel" if "rows_kernel" in kn else "decode_kernel<slow>") + " lds=%s grid=%s" % (r["LDS_Block_Size"], r["Grid_Size"])
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for name, cs in agg.items():
         for k, v in cs.items():
-            out.setdefault(name, {})[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+            out.setdefault(name, {})[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v), "sum": sum(v)}
 json.dump(out, open("profiles/%s_eu8g_pmc.json" % tag, "w"), indent=1)
 b = json.loads(open("profiles/%s_eu8g_bench.json" % tag).read())
 arcs = b["config"]["arcs_per_gpu"]
@@ -30,11 +36,11 @@ v = out[t0]
 print("tier0:", t0)
 print("  VALU/arc %.2f  SALU/arc %.2f  active lanes %.3f" % (v["SQ_INSTS_VALU"]["mean_per_launch"] / arcs, v["SQ_INSTS_SALU"]["mean_per_launch"] / arcs,
       v["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / 64 / v["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]))
-# FETCH_SIZE per scan: the counter pass ran (1 gate + 2 timed) scans; each dispatch appears once per scan
-fetch = sum(c["FETCH_SIZE"]["mean_per_launch"] for c in out.values() if "FETCH_SIZE" in c)
-print("  FETCH_SIZE (KB, one launch of every tier kernel) %.4g -> x1024 x2 = %.4g bytes" % (fetch, fetch * 2048))
+# FETCH_SIZE of the last scan: every decode dispatch after the second-to-last tier-0 launch
+fetch = sum(c["FETCH_SIZE"]["sum"] for c in out.values() if "FETCH_SIZE" in c)
+print("  FETCH_SIZE (KB, all launches of the last scan) %.4g -> x1024 x2 = %.4g bytes" % (fetch, fetch * 2048))
 json.dump({"eu": {"hbm_bytes_per_launch": fetch * 2048,
-                  "note": "FETCH_SIZE summed over the tier kernels of one scan, x1024 B, x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section)"}},
+                  "note": "FETCH_SIZE summed over every decode launch of the last scan of the counter pass, x1024 B, x2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section)"}},
           open("profiles/traffic.json", "w"), indent=1)
 print("  bench:", b["value"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["frac"], "cpu", b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"])
 for k in ("web", "w0"):
