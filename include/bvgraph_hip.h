@@ -132,6 +132,14 @@ int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
  * IG:405-436; cf. algo/HyperBall.java:748-768): bounds[0..k], bounds[0]=0, bounds[k]=nodes. */
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);
 
+/* ---- transposition feed (the decode + sort of Transform.transposeOffline, Transform.java:1058-1160; processBatch :938) ----
+ * Decodes every arc (x,y) of the graph on the device, sorts the pairs by target (stable radix sort, so sources stay increasing)
+ * and returns the TRANSPOSE in CSR form: toffsets[nodes+1] = exclusive prefix of the in-degrees, tsucc[arcs] = for each node y
+ * the sources of its incoming arcs in increasing order (what ArcListASCIIGraph / BVGraph.store of the transpose would list).
+ * tsucc may be NULL to query *n_arcs (returns BVG_E_CAPACITY).  Requires node_base == 0.  _dev: both buffers in device memory. */
+int bvg_transpose(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint64_t tsucc_cap, uint64_t* n_arcs);
+int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t tsucc_cap, uint64_t* n_arcs);
+
 /* ---- synthetic-workload helper (bench only): K back-to-back copies of the graph ----
  * BV records are translation invariant (every value is coded relative to the node id, Appendix A.3
  * of SURVEY.md), so the concatenation of K copies of the bit stream is a valid BVGraph with K*nodes

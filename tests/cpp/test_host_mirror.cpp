@@ -58,6 +58,19 @@ int main(int argc, char** argv) {
                 o += ra.size();
             }
         }
+        {   // transposition feed: every arc (x,y) must appear as x in y's incoming list, lists increasing, same arc count
+            std::vector<uint64_t> toff; std::vector<int64_t> ts;
+            g->transposeCSR(toff, ts);
+            if (toff.size() != (size_t)n + 1 || toff[(size_t)n] != arcs || ts.size() != arcs) { printf("FAIL transpose size\n"); return 1; }
+            for (int64_t y = 0; y < n; y++) for (uint64_t t = toff[(size_t)y] + 1; t < toff[(size_t)y + 1]; t++) if (ts[t - 1] >= ts[t]) { printf("FAIL transpose order\n"); return 1; }
+            for (int64_t x : {(int64_t)0, n / 2, n - 1}) {
+                for (int64_t y : g->successorBigArray(x)) {
+                    bool found = false;
+                    for (uint64_t t = toff[(size_t)y]; t < toff[(size_t)y + 1] && !found; t++) found = ts[t] == x;
+                    if (!found) { printf("FAIL transpose arc\n"); return 1; }
+                }
+            }
+        }
         threw = false;
         try { g->outdegree(n); } catch (const std::invalid_argument&) { threw = true; }
         if (!threw) { printf("FAIL no IllegalArgumentException\n"); return 1; }

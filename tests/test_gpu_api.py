@@ -261,3 +261,39 @@ def test_offsets_are_derived_when_absent(W, tools, oracle, tmp_path, cnr_csr):
     assert np.array_equal(q.offsets(), st.offsets)
     q2 = W.BVGraph.load_offline(base)
     assert q2.scan()["arcs"] == st.stats["arcs"]
+
+
+def _cpu_transpose(n, deg, succ):
+    src = np.repeat(np.arange(n, dtype=np.int64), deg)
+    order = np.argsort(succ, kind="stable")                       # stable: sources stay increasing inside every target
+    toff = np.concatenate([[0], np.cumsum(np.bincount(succ, minlength=n))]).astype(np.uint64)
+    return toff, src[order]
+
+
+def test_transpose_feed_matches_cpu_transpose(W, tools, oracle, small):
+    """decode + device sort = Transform.transposeOffline's batches (Transform.java:1058-1160)."""
+    g, og, lists, st = small
+    n = g.num_nodes()
+    deg, succ = og.decode_range(0, n)
+    toff, tsucc = g.transpose()
+    ctoff, ctsucc = _cpu_transpose(n, deg, succ)
+    assert np.array_equal(toff, ctoff) and np.array_equal(tsucc, ctsucc)
+    # transposing twice gives the graph back (TransformTest's involution check)
+    t = tools.store((toff.astype(np.int64), tsucc), W.default_params())
+    gt = W.BVGraph.from_memory(t.params, t.graph, t.offsets)
+    toff2, tsucc2 = gt.transpose()
+    assert np.array_equal(toff2, np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64)) and np.array_equal(tsucc2, succ)
+    gt.close()
+    # degenerate inputs and the shard restriction
+    for ls in ([], [[]], [[0]], [[1], [0]], [[] for _ in range(70)]):
+        s2 = tools.store(ls, W.default_params())
+        g2 = W.BVGraph.from_memory(s2.params, s2.graph, s2.offsets)
+        to, ts = g2.transpose()
+        d2 = np.array([len(l) for l in ls], dtype=np.int64); a2 = np.array([v for l in ls for v in l], dtype=np.int64)
+        cto, cts = _cpu_transpose(len(ls), d2, a2) if len(ls) else (np.zeros(1, np.uint64), np.zeros(0, np.int64))
+        assert np.array_equal(to, cto) and np.array_equal(ts, cts), ls
+        g2.close()
+    g.set_node_base(5)
+    with pytest.raises(W.IllegalArgumentException):
+        g.transpose()
+    g.set_node_base(0)

@@ -128,3 +128,14 @@ def test_degenerate_graphs(W, tools, oracle):
         if lists:
             og = _oracle_graph(oracle, st)
             assert r["chk"] == og.scan()["chk"]
+
+
+def test_cnr2000_transpose(cnr_gpu, cnr_csr):
+    """The golden graph transposed on the device against numpy on the golden adjacency."""
+    gdeg, gsucc = cnr_csr
+    n = len(gdeg)
+    toff, tsucc = cnr_gpu.transpose()
+    src = np.repeat(np.arange(n, dtype=np.int64), gdeg)
+    order = np.argsort(gsucc, kind="stable")
+    assert np.array_equal(toff, np.concatenate([[0], np.cumsum(np.bincount(gsucc, minlength=n))]).astype(np.uint64))
+    assert np.array_equal(tsucc, src[order])

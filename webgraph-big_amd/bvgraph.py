@@ -115,6 +115,8 @@ def lib():
         L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
         L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
+        L.bvg_transpose.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_transpose_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_tile.argtypes = [vp, i64, pp]
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
@@ -440,6 +442,19 @@ class BVGraph:
         b = np.empty(k + 1, dtype=np.int64)
         _check(lib().bvg_split_by_bits(self._h, k, b.ctypes.data), "split_by_bits")
         return b
+
+    def transpose(self):
+        """The transpose in CSR form (toffsets uint64[n+1], tsucc int64[arcs]): the decode + sort of Transform.transposeOffline
+        (Transform.java:1058-1160) done on the device; sources of every node's incoming arcs in increasing order."""
+        n = self.num_nodes()
+        toff = np.empty(n + 1, dtype=np.uint64)
+        need = C.c_uint64(0)
+        st = lib().bvg_transpose(self._h, toff.ctypes.data, None, 0, C.byref(need))
+        if st not in (0, _abi.E_CAPACITY):
+            _check(st, "transpose")
+        tsucc = np.empty(max(int(need.value), 1), dtype=np.int64)
+        _check(lib().bvg_transpose(self._h, toff.ctypes.data, tsucc.ctypes.data, len(tsucc), C.byref(need)), "transpose")
+        return toff, tsucc[:int(need.value)]
 
     def scan(self, frm=0, to=None):
         """Full sequential successor scan consumed on chip (SpeedTest.java:127-141): dict of bvg_scan_result."""

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cctype>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +89,7 @@ struct bvg_graph {
     static constexpr int kSide = 5;            // [0] giants (global-memory kernel), [1..4] one per LDS size class
     hipStream_t side[kSide] = {}; hipEvent_t side_ev[kSide] = {};
     void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
+    void* tr_ws = nullptr; size_t tr_ws_bytes = 0;   // bvg_transpose workspace, kept between calls
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     struct Pred {
         uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
@@ -800,6 +802,7 @@ void bvg_close(bvg_graph* g) {
     if (g->stream) { (void)hipStreamSynchronize(g->stream); (void)hipStreamDestroy(g->stream); }
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->tr_ws) (void)hipFree(g->tr_ws);
     if (g->d_acc) (void)hipFree(g->d_acc);
     if (g->d_fail) (void)hipFree(g->d_fail);
     if (g->slow_ws) (void)hipFree(g->slow_ws);
@@ -938,6 +941,85 @@ int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) {
     HIPCHK(hipMemcpy(&b[1], sh->d_offsets + to, sizeof(uint64_t), hipMemcpyDeviceToHost));
     out->graph_bytes = (b[1] + 7) / 8 - b[0] / 8;
     return r;
+}
+
+static int transpose_impl(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint64_t cap, uint64_t* n_arcs, bool dev) {
+    if (!g || !toffsets) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    if (g->node_base != 0) return BVG_E_ARG;                 // a shard's targets leave its node range: transpose the whole graph
+    const int64_t n = sh->p.nodes;
+    HIPCHK(hipSetDevice(sh->device));
+    const bool dbgt = getenv("BVG_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto tA = now();
+    // One workspace per handle, grown on demand and kept between calls (a fresh multi-gigabyte hipMalloc costs far more
+    // than the decode and the sort together): [deg | cum | scan tmp | bad] first, the arc-sized part once the arc count is known.
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_deg = 0, o_cum = o_deg + al(nn * sizeof(int32_t)), o_tmp = o_cum + al((nn + 1) * sizeof(uint64_t));
+    const size_t o_bad = o_tmp + al(scan_tmp_elems((int64_t)nn) * sizeof(uint64_t)), o_arcs = o_bad + 256;
+    auto ensure = [&](size_t bytes) -> int {
+        if (bytes <= g->tr_ws_bytes) return 0;
+        if (g->tr_ws) { (void)hipFree(g->tr_ws); g->tr_ws = nullptr; g->tr_ws_bytes = 0; }
+        if (hipMalloc(&g->tr_ws, bytes) != hipSuccess) { (void)hipGetLastError(); return BVG_E_NOMEM; }
+        g->tr_ws_bytes = bytes;
+        return 0;
+    };
+    int rc = ensure(o_arcs); if (rc) return rc;
+    auto at = [&](size_t off) { return (char*)g->tr_ws + off; };
+    HIPCHK(hipMemsetAsync(at(o_bad), 0, sizeof(unsigned), g->stream));
+    HIPCHK(hipMemsetAsync(at(o_cum), 0, (nn + 1) * sizeof(uint64_t), g->stream));
+    uint64_t total = 0;
+    if (n > 0) {
+        launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, 0, n, sh->p.outdegree_coding, (int32_t*)at(o_deg), nullptr, g->stream);
+        launch_exclusive_scan((const int32_t*)at(o_deg), (uint64_t*)at(o_cum), n, (uint64_t*)at(o_tmp), g->stream);
+        HIPCHK(hipMemcpyAsync(&total, (uint64_t*)at(o_cum) + n, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (n_arcs) *n_arcs = total;
+    if (total > cap || (!tsucc && total > 0)) return BVG_E_CAPACITY;
+    const size_t mm = (size_t)(total ? total : 1);
+    const size_t temp_b = transpose_temp_bytes(total, n > 0 ? n : 1);
+    const size_t o_succ = o_arcs, o_src = o_succ + al(mm * 8), o_keys = o_src + al(mm * 8), o_temp = o_keys + al(mm * 8);
+    const size_t o_toff = o_temp + al(temp_b ? temp_b : 16), o_ts = o_toff + (dev ? 0 : al((nn + 1) * 8)), o_end = o_ts + (dev ? 0 : al(mm * 8));
+    {   // growing the workspace must not lose the prefix sums: save them on the host side of the copy only when it really grows
+        if (o_end > g->tr_ws_bytes) {
+            std::vector<char> keep(o_arcs);
+            HIPCHK(hipMemcpy(keep.data(), g->tr_ws, o_arcs, hipMemcpyDeviceToHost));
+            rc = ensure(o_end); if (rc) return rc;
+            HIPCHK(hipMemcpy(g->tr_ws, keep.data(), o_arcs, hipMemcpyHostToDevice));
+        }
+    }
+    uint64_t* const d_cum = (uint64_t*)at(o_cum); int64_t* const d_succ = (int64_t*)at(o_succ);
+    uint64_t* const d_toff = dev ? toffsets : (uint64_t*)at(o_toff); int64_t* const d_tsucc = dev ? tsucc : (int64_t*)at(o_ts);
+    const auto tB = now();
+    if (n > 0) {                                             // the decode: every successor list, source-major, stays in HBM
+        rc = run_decode(g, 0, n, true, d_cum, d_succ, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    const auto tC = now();
+    if (transpose_pairs(d_cum, n, total, d_succ, (int64_t*)at(o_src), (uint64_t*)at(o_keys), at(o_temp), temp_b, d_toff, d_tsucc, (unsigned*)at(o_bad), g->stream) != hipSuccess) {
+        (void)hipGetLastError(); return BVG_E_HIP;
+    }
+    unsigned bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, at(o_bad), sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    const auto tD = now();
+    if (dbgt) fprintf(stderr, "[bvg] transpose: outdegrees + workspace %.1f ms, decode %.1f ms, expand + sort + offsets %.1f ms\n", ms(tA, tB), ms(tB, tC), ms(tC, tD));
+    if (bad) return BVG_E_EOF;                               // a successor outside [0,n): malformed stream
+    if (!dev) {
+        HIPCHK(hipMemcpy(toffsets, d_toff, (size_t)(n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        if (total) HIPCHK(hipMemcpy(tsucc, d_tsucc, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+int bvg_transpose(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint64_t tsucc_cap, uint64_t* n_arcs) {
+    return transpose_impl(g, toffsets, tsucc, tsucc_cap, n_arcs, false);
+}
+int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t tsucc_cap, uint64_t* n_arcs) {
+    return transpose_impl(g, (uint64_t*)d_toffsets, (int64_t*)d_tsucc, tsucc_cap, n_arcs, true);
 }
 
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) {

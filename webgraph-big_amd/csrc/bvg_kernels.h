@@ -86,4 +86,9 @@ void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
 void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);
 
+// transposition feed (bvg_transpose.hip): stable radix sort of (target, source) pairs + in-degree prefix
+size_t transpose_temp_bytes(uint64_t arcs, int64_t n);
+hipError_t transpose_pairs(const uint64_t* cum, int64_t n, uint64_t arcs, const int64_t* succ, int64_t* src, uint64_t* keys_out, void* temp, size_t temp_bytes,
+                           uint64_t* toffsets, int64_t* tsucc, unsigned* d_bad, hipStream_t s);
+
 }  // namespace bvg

@@ -133,6 +133,15 @@ public:
         succ.resize((size_t)need);
         if (need) check(bvg_successors_batch(h_, nodes.data(), (int64_t)nodes.size(), deg.data(), succ.data(), need, &need), "successors_batch");
     }
+    // the transpose in CSR form (decode + device sort; Transform.transposeOffline, Transform.java:1058-1160)
+    void transposeCSR(std::vector<uint64_t>& toffsets, std::vector<int64_t>& tsucc) {
+        toffsets.resize((size_t)p_.nodes + 1);
+        uint64_t need = 0;
+        int st = bvg_transpose(h_, toffsets.data(), nullptr, 0, &need);
+        if (st != BVG_E_CAPACITY) check(st, "transpose");
+        tsucc.resize((size_t)need);
+        if (need) check(bvg_transpose(h_, toffsets.data(), tsucc.data(), need, &need), "transpose");
+    }
     NodeIterator nodeIterator(int64_t from = 0) { return NodeIterator(shared_from_this(), from, INT64_MAX); }   // BVGraph.java:1257
     std::vector<NodeIterator> splitNodeIterators(int howMany) {                            // ImmutableGraph.java:405-436
         std::vector<NodeIterator> v; const int64_t n = p_.nodes, m = (n + howMany - 1) / howMany;
