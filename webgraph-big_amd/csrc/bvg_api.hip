@@ -352,6 +352,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const double avg_d = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
         a.emit_tasks = (sh->p.window_size == 0 || avg_d >= 24.0) ? 1u : 0u;
         if (getenv("BVG_EMIT")) a.emit_tasks = (uint32_t)strtoul(getenv("BVG_EMIT"), nullptr, 10) ? 1u : 0u;
+        a.pass_cost = getenv("BVG_PASSCOST") ? (uint32_t)strtoul(getenv("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
     if (!batch && rows_default && pl.skip_total && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state)) {

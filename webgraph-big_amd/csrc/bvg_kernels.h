@@ -41,6 +41,7 @@ struct DecodeArgs {
     uint32_t lds_stage_words;           // row-static kernel: LDS window over the stream, in dwords (multiple of 4)
     uint32_t grab_threshold;            // stream kernel: idle lanes that trigger a batched grab
     uint32_t batch;                     // 1 = bvg_successors_batch: block 2i is request i; outputs are indexed by request
+    uint32_t pass_cost;                 // task emission: assumed fixed cost of one level pass, in merge steps (per-row choice of the emission form)
     uint32_t emit_tasks;                // 1 = row kernel variant with level-synchronous task emission (chosen per row), 0 = pipelined loop only
     uint32_t dbg;                       // timing experiments only (BVG_DBG): 1 skip emission, 2 skip residual decode, 4 skip parse, 16 force task rows, 32 force pipelined rows, 64 work counters, 128 skip the task merge loop
     // residual skip index (row kernel): for every node with >= kSkipMin residuals, one entry per kSkipEvery residuals

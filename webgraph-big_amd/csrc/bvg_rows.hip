@@ -37,7 +37,6 @@ constexpr uint32_t kInf = 0xFFFFFFFFu;
 constexpr uint32_t LIN = 0xFFFFFFFFu;          // linear window: no index mask
 constexpr uint32_t RM = kRing - 1;
 constexpr uint32_t kMinTask = 4;               // shortest task (outputs) worth a seek
-constexpr uint32_t kPassCost = 14;             // fixed cost of one level pass of the task emission, in merge steps
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
@@ -482,7 +481,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             const uint32_t rowW = wave_sum32(emitn ? d : 0u);
             {
                 const uint32_t maxd = wave_max32(emitn ? d : 0u), nlev = wave_max32(emitn ? lvl + 1u : 0u);
-                const uint32_t est = ((rowW * 21u) >> 10) + nlev * kPassCost;
+                const uint32_t est = ((rowW * 21u) >> 10) + nlev * a.pass_cost;
                 by_tasks = (est < maxd || (a.dbg & 16u)) && !(a.dbg & 32u);
             }
             uint32_t emitted = 0;
