@@ -283,7 +283,9 @@ struct SynthSource : ListSource {
             if (missing > 0 && rng.unit() < sp.p_interval) {
                 int64_t l = 4 + (int64_t)rng.geometric(sp.interval_len); if (l > missing) l = missing;
                 int64_t start = x + bvg_nat_shift((int64_t)rng.geometric(30.0));
-                if (start < 0) start = 0; if (start + l > n) start = n - l; if (start < 0) { start = 0; l = n; }
+                if (start < 0) start = 0;
+                if (start + l > n) start = n - l;
+                if (start < 0) { start = 0; l = n; }
                 for (int64_t t = 0; t < l; t++) out.push_back(start + t);
                 missing -= l;
             }
