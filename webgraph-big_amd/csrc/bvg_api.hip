@@ -45,7 +45,8 @@ struct Plan {
     uint64_t version = 0;
     // residual skip index (built by two passes of the row kernel the first time a large range is decoded)
     int skip_state = 0;                       // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index)
-    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint32_t* d_skip_bit = nullptr; uint64_t* d_skip_val = nullptr;
+    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint32_t* d_skip_bit = nullptr; void* d_skip_val = nullptr;
+    bool skip_wide = false;                   // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
     std::vector<uint64_t> h_skip_first;
     void release_skip() {
         if (d_skip_first) (void)hipFree(d_skip_first);
@@ -279,6 +280,7 @@ int build_skip(bvg_graph* g) {
     const uint32_t nblk = pl.nblk;
     const int64_t n = sh->p.nodes;
     if (!nblk || n == 0) { pl.skip_state = 1; return 0; }
+    const bool build_wide = sh->wide || g->tun.force_wide;
     uint32_t* d_cnt = nullptr;
     HIPCHK(hipMalloc(&d_cnt, (size_t)nblk * sizeof(uint32_t)));
     HIPCHK(hipMemset(d_cnt, 0, (size_t)nblk * sizeof(uint32_t)));
@@ -294,16 +296,16 @@ int build_skip(bvg_graph* g) {
     const uint64_t total = first[nblk];
     if (total == 0) { pl.skip_state = 1; return 0; }
     if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&pl.d_skip_val, total * sizeof(uint64_t)) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; (void)hipGetLastError(); return 0; }
+        hipMalloc(&pl.d_skip_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; (void)hipGetLastError(); return 0; }
     if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; return 0; }
-    pl.skip_total = total;
+    pl.skip_total = total; pl.skip_wide = build_wide;
     g->skip_mode = 2;
     r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr);
     g->skip_mode = 0;
     if (r) { pl.release_skip(); pl.skip_state = 1; return 0; }
     pl.h_skip_first.swap(first);
     pl.skip_state = 1;
-    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * 12.0 / 1048576.0);
+    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * (build_wide ? 12.0 : 8.0) / 1048576.0);
     return 0;
 }
 
@@ -355,7 +357,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         a.pass_cost = getenv("BVG_PASSCOST") ? (uint32_t)strtoul(getenv("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
-    if (!batch && rows_default && pl.skip_total && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state)) {
+    if (!batch && rows_default && pl.skip_total && pl.skip_wide == wide && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state)) {
         a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val;
     }
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
@@ -607,7 +609,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;
         res->index_bytes = (uint64_t)(to - from + 1) * 8 + (uint64_t)nblocks * 20;
-        if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * 12 + (uint64_t)nblocks * 8;
+        if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * (4 + esz) + (uint64_t)nblocks * 8;
         res->graph_bytes = 0;
     }
     if (acc[3] && getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] error bits 0x%llx\n", acc[3]);

@@ -48,7 +48,7 @@ struct DecodeArgs {
     // {bit offset of that residual's code from the record start, value of the residual before it}; entries of a block
     // are contiguous, in node order.  skip_mode 1 = count entries per block, 2 = fill them, 0 = use them when present.
     const uint64_t* skip_first;         // nblk+1 entry indices, or nullptr
-    uint32_t* skip_bit; void* skip_val; // entries (skip_val: 8 bytes per entry whatever the successor type)
+    uint32_t* skip_bit; void* skip_val; // entries (skip_val: one successor-typed value per entry, 4 or 8 bytes)
     uint32_t* skip_cnt;                 // skip_mode 1: per-block entry count out
     uint32_t skip_mode;
 };

@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     uint32_t trel = t_rel; T r = (T)(r0 + nl);
                     if (q) {
                         const uint64_t e = sk_base + t_ef + q - 1u;
-                        trel = t_rec + a.skip_bit[e]; r = (T)reinterpret_cast<const uint64_t*>(a.skip_val)[e];
+                        trel = t_rec + a.skip_bit[e]; r = reinterpret_cast<const T*>(a.skip_val)[e];
                         if (!(trel > t_rel && trel < t_pend)) tbad = true;
                     }
                     T* const tail = pool + t_dst + t0;
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (a.skip_mode == 2 && cntE && t && (t & (kSkipEvery - 1u)) == 0) {  // fill the skip entry of this residual
                         const uint32_t ei = efirst + (t / kSkipEvery) - 1u;                // inside the block's allotment only: a block
                         if (ei < sk_n) {                                                    // that ends in the generic kernel has none
-                            a.skip_bit[sk_base + ei] = rel - recrel; reinterpret_cast<uint64_t*>(a.skip_val)[sk_base + ei] = (uint64_t)r;
+                            a.skip_bit[sk_base + ei] = rel - recrel; reinterpret_cast<T*>(a.skip_val)[sk_base + ei] = r;
                         }
                     }
                     uint64_t val;
