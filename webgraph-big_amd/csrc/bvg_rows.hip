@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         // their nodes are simply parsed again at the head of the next row.
         uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0, di = 0;
         int64_t extra = d;
+        bool malf = false;                                                   // counts that contradict each other (position tasks need them exact)
         const bool parse = needed && lane < k && d > 0 && !(a.dbg & 4);
         // ---- A: reference and block count (BVG:1015-1021)
         if (parse) {
@@ -276,9 +277,11 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     tot += b;
                     if (!(i & 1)) copied += b;
                 }
-                if (!(bc & 1)) copied += (int64_t)nd_d[(uint32_t)(x - ref) & RM] - tot;      // BVG:1030
+                const int64_t rlen_ = (int64_t)nd_d[(uint32_t)(x - ref) & RM];
+                if (!(bc & 1)) copied += rlen_ - tot;                         // BVG:1030
                 extra = (int64_t)d - copied;
-                if (extra < 0 || copied < 0) { err |= ERR_MALFORMED; extra = 0; }       // never let a tail start before the list
+                if (tot > rlen_) malf = true;                                 // blocks running past the referenced list
+                if (extra < 0 || copied < 0) { err |= ERR_MALFORMED; extra = 0; malf = true; }       // never let a tail start before the list
             }
             if (extra > 0 && minint != 0) {                                   // always gamma
                 const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     extra -= len; di += (uint32_t)len;
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
-                if (extra < 0) { err |= ERR_MALFORMED; extra = 0; }
+                if (extra < 0) { err |= ERR_MALFORMED; extra = 0; malf = true; }
             }
             nres = (uint32_t)extra;
         }
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 // lists grow from the bottom of the pool; the row's residual values are parked top-down and die
                 // with the row (tasks of one node run concurrently, so they cannot share the list's own tail)
                 size = (needed && lane < k && stored) ? dclamp : 0u;
-                const uint32_t rsz = (needed && lane < k) ? (nres > CAP ? CAP + 1 : nres) : 0u;
+                const uint32_t rsz = (needed && lane < k) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // + the guard slot of the position tasks
                 sincl = wave_incl_scan32(size);
                 const uint32_t rincl = wave_incl_scan32(rsz);
                 rtb = CAP - (rincl > CAP ? CAP : rincl);
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             failed = true;
             {
                 uint32_t d0 = lane_get(d, 0); const uint32_t n0 = lane_get(nres, 0);
-                if (TASK && d0 <= 0x3FFFFFFFu) d0 += n0 > d0 ? d0 : n0;
+                if (TASK && d0 <= 0x3FFFFFFFu) d0 += (n0 > d0 ? d0 : n0) + 1u;
                 fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64;
             }
             break;
@@ -453,17 +456,28 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         BVG_T1(5, tq5);
         bool by_tasks = false;
         if constexpr (TASK) {
-            // Level-synchronous emission by TASKS.  Nodes are grouped by their depth in the row's reference forest;
-            // within a level every node is cut into tasks of ~S outputs (value ranges delimited by splitters taken
-            // from its longest stream) and the tasks, not the nodes, are dealt to the lanes, so a row costs about
-            // (successors in the row)/64 merge steps per level instead of its longest list.  A task seeks the three
-            // streams to its first splitter (block walk for the mask, lower bounds for list/residuals) and then runs
-            // the same three-way merge (MergedLongIterator.java:63-92) until the next splitter.
+            // Level-synchronous emission by POSITION.  Nodes are grouped by their depth in the row's reference forest.  The
+            // successor list of a node is the masked copy of the referenced list with the extras (residuals, intervals)
+            // inserted (BVG:1062-1090), and the three streams are disjoint in a well-formed file, so every extra knows its
+            // place without a merge: (extras below it) + (copied elements below it).  Per level:
+            //   Z1  one lane per EXTRA (residual value or interval): lower bound in the referenced list + rank under the copy
+            //       mask give its output position; residual values are stored (and summed) right there, positions are kept;
+            //   Z2  one lane per TASK of S consecutive output positions, all tasks of a level equally long: a position is
+            //       a residual (done), falls into an interval, or takes the next kept element of the referenced list.
+            // An extra that meets a copied element or another extra (which the reference's merge would emit once,
+            // MergedLongIterator.java:85-89) sends the block to the generic kernel, which follows the iterators literally.
             uint32_t* const tmap = produced;
+            constexpr uint32_t HS = sizeof(T) * 4;                            // interval entry: length | position << HS
+            const T HM = (T)(((T)1 << HS) - 1);
             const uint32_t tq0 = BVG_T0();
             uint32_t rlbN = 0, rlenN = 0;
             if (act && ref > 0) { const int64_t y = x - ref; rlbN = nd_base[(uint32_t)y & RM]; rlenN = nd_d[(uint32_t)y & RM]; }
-            const uint32_t rtbN = rtb;
+            // A node without reference is its residuals merged with its intervals (BVG:1087-1089): the parked residual
+            // values play the role of an unmasked "referenced list", the intervals are the only extras to place (and the
+            // guard serves as its empty array of residual positions).
+            const bool pure = act && ref == 0;
+            if (pure) { rlbN = rtb; rlenN = nres; }
+            const uint32_t rtbN = pure ? rtb + nres : rtb, nresN = pure ? 0u : nres;
             const bool inrow = act && ref > 0 && ref <= lane;
             uint32_t lvl = 0;
             for (int it = 0; it < 64; it++) {
@@ -473,10 +487,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 if (!ballot(ch)) break;
             }
             const bool emitn = act && d > 0 && !(a.dbg & 1);
-            uint32_t axis = 0, la = rlenN;                                    // the longest stream gives the splitters
-            if (nres > la) { la = nres; axis = 1; }
-            if (di > la) { la = di; axis = 2; }
-            // Tasks pay a fixed cost per level (seeks, task map); the pipelined node-per-lane loop below costs about the
+            // Position tasks pay a fixed cost per level (maps, seeks); the pipelined node-per-lane loop below costs about the
             // longest list of the row.  Estimate both and take the cheaper one for this row.
             const uint32_t rowW = wave_sum32(emitn ? d : 0u);
             {
@@ -484,34 +495,98 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 const uint32_t est = ((rowW * 21u) >> 10) + nlev * a.pass_cost;
                 by_tasks = (est < maxd || (a.dbg & 16u)) && !(a.dbg & 32u);
             }
-            uint32_t emitted = 0;
+            bool zbad = malf;
             uint64_t remaining = by_tasks ? ballot(emitn) : 0ull;
+            if (by_tasks && act) pool[rtb + nres] = sentinel<T>();            // guard behind the node's residual positions
             BVG_T1(0, tq0);
             for (uint32_t L = 0; remaining; L++) {
                 const uint32_t tq1 = BVG_T0();
                 const bool mem = emitn && lvl == L;
                 remaining &= ~ballot(mem);
+                // ---------------- Z1: one lane per extra
+                {
+                    const uint32_t In = mem ? nresN + ic : 0u;
+                    const uint32_t iincl2 = wave_incl_scan32(In), is = iincl2 - In, Itot = lane_get(iincl2, 63);
+                    for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
+                        {
+                            const uint32_t q0 = is < p0 ? p0 - is : 0u;
+                            const uint32_t q1 = is >= p0 + 64u ? 0u : (is + In > p0 + 64u ? p0 + 64u - is : In);
+                            for (uint32_t q = q0; q < q1; q++) tmap[is + q - p0] = lane | (q << 8);
+                        }
+                        __syncthreads();
+                        const bool tl = p0 + lane < Itot;
+                        const uint32_t ent = tl ? tmap[lane] : lane;
+                        const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                        const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64);
+                        const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
+                        const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
+                        const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1), nl, 64);
+                        const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                        const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
+                        T v = 0; uint32_t len = 1, pe = 0; bool isiv = false;
+                        if (tl) {
+                            uint32_t eb;
+                            if (q < t_ic) {                                   // interval q: the intervals and residuals below it
+                                isiv = true;
+                                v = scr[t_ib + 2 * q]; len = (uint32_t)(scr[t_ib + 2 * q + 1] & HM);
+                                eb = 0;
+                                for (uint32_t i = 0; i < q; i++) eb += (uint32_t)(scr[t_ib + 2 * i + 1] & HM);
+                                const uint32_t lb = lds_lower_bound<T>(rt, t_nres, v);
+                                if (lb < t_nres && (T)(rt[lb] - v) < (T)len) zbad = true;          // a residual inside the interval
+                                eb += lb;
+                            } else {                                          // residual q - ic
+                                const uint32_t i = q - t_ic;
+                                v = rt[i]; eb = i;
+                                for (uint32_t kk = 0; kk < t_ic; kk++) {
+                                    const T left = scr[t_ib + 2 * kk]; const uint32_t ln = (uint32_t)(scr[t_ib + 2 * kk + 1] & HM);
+                                    if (left <= v) { eb += ln; if ((T)(v - left) < (T)ln) zbad = true; }
+                                }
+                            }
+                            uint32_t t = 0;
+                            if (t_rlen) {                                     // copied elements below v: rank of its lower bound under the mask
+                                const uint32_t qq = lds_lower_bound<T>(rl, t_rlen, v);
+                                uint32_t pos = 0, qn = qq; bool kp = true, in = false;
+                                for (uint32_t bq = 0; bq < t_bc; bq++) {
+                                    const uint32_t bl = (uint32_t)scr[t_sb + bq];
+                                    if (pos + bl > qq) { if (kp) t += qq - pos; else qn = pos + bl; in = true; break; }
+                                    if (kp) t += bl;
+                                    pos += bl; kp = !kp;
+                                }
+                                if (!in) { if (kp) t += qq - pos; else qn = t_rlen; }
+                                if (qn < t_rlen && (T)(rl[qn] - v) < (T)len) zbad = true;           // a copied element meets the extra
+                            }
+                            pe = eb + t;
+                            if (pe + len > t_d) { zbad = true; pe = 0; len = 0; }
+                        }
+                        __syncthreads();                                      // the parked values have been read: positions may replace them
+                        if (tl && len) {
+                            if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
+                            else {
+                                if (t_fl & 1u) pool[t_ob + pe] = v;
+                                if (!MAT && (t_fl & 2u)) blk_chk += mix_node<T>(t_k0, t_k1, v, nb_lo, nbz);
+                                rt[q - t_ic] = (T)pe;
+                            }
+                        }
+                        cnt_seek++;
+                        __syncthreads();
+                    }
+                }
+                BVG_T1(3, tq1);
+                const uint32_t tq1b = BVG_T0();
+                // ---------------- Z2: tasks of S output positions
                 const uint32_t Wl = wave_sum32(mem ? d : 0u);
-                // S: (about) the smallest task length for which the level's tasks fit the 64 lanes in one pass
-                uint32_t S = (Wl * 5u + 255u) >> 8; if (S < kMinTask) S = kMinTask;    // start a little above W/64: one probe usually
-                for (int it = 0; it < 4; it++) {
-                    uint32_t tn = 0;
-                    if (mem) { tn = (uint32_t)((float)d / (float)S); if (tn * S < d) tn++; }
-                    const uint32_t tt = wave_sum32(tn);
-                    if (tt <= 64u) break;
+                uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
+                uint32_t Tn = 0;
+                for (int it = 0; it < 6; it++) {
+                    Tn = 0;
+                    if (mem) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
+                    const uint32_t tt = wave_sum32(Tn);
+                    if (tt <= 64u || it == 5) break;
                     const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
                     S = s2 > S ? s2 : S + 1u;
                 }
-                uint32_t Tn = 0, step = 1;
-                if (mem) {
-                    step = (uint32_t)((float)S * (float)la / (float)d); if (step < 1u) step = 1u;
-                    Tn = (uint32_t)((float)la / (float)step);
-                    while (Tn * step < la) Tn++;
-                    while (Tn > 1u && (Tn - 1u) * step >= la) Tn--;
-                    if (Tn == 0) Tn = 1;
-                }
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
-                BVG_T1(1, tq1);
+                BVG_T1(1, tq1b);
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
                     const uint32_t tq2 = BVG_T0();
                     {   // task map of this pass: (node lane, task index inside the node)
@@ -525,102 +600,80 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
                     const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64);
                     const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
-                    const uint32_t t_nres = __shfl(nres, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
-                    const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1) | (axis << 2), nl, 64);
-                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64), t_step = __shfl(step, nl, 64), t_la = __shfl(la, nl, 64);
-                    const bool t_stored = t_fl & 1u, t_rep = (t_fl >> 1) & 1u; const uint32_t t_axis = t_fl >> 2;
+                    const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
+                    const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1), nl, 64);
+                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                    const bool t_stored = t_fl & 1u, t_rep = (t_fl >> 1) & 1u;
                     const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
-                    uint32_t rpos = 0, keep = kInf, bi = 0, j = 0, j0 = 0, rsi = 0, ivrem = 0, ivi = t_ic;
-                    T ivcur = 0, rhead = sentinel<T>(), vend = sentinel<T>();
+                    uint32_t p = 0, pstop = 0, ri = 0, rnext = kInf, ivk = t_ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = t_bc;
+                    T ivleft = 0;
                     if (tl) {
-                        if (t_bc > 0) {                                       // MaskedLongIterator.java:73-78
-                            keep = (uint32_t)scr[t_sb]; bi = 1;
-                            if (keep == 0) {
-                                if (bi >= t_bc) rpos = t_rlen;
-                                else { rpos += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; } }
-                            }
+                        p = q * S; pstop = p + S < t_d ? p + S : t_d;
+                        ri = lds_lower_bound<T>(rt, t_nres, (T)p);            // residual positions below p
+                        rnext = (uint32_t)rt[ri];                             // (the guard reads as kInf)
+                        uint32_t ie = 0;
+                        for (uint32_t i = 0; i < t_ic; i++) {                 // interval elements below p; the interval at / after p
+                            const T pk = scr[t_ib + 2 * i + 1];
+                            const uint32_t ln = (uint32_t)(pk & HM), ps = (uint32_t)(pk >> HS);
+                            if (ps + ln > p) { ivk = i; ivpos = ps; ivlen = ln; ivleft = scr[t_ib + 2 * i]; if (p > ps) ie += p - ps; break; }
+                            ie += ln;
                         }
-                        const uint32_t lo = q * t_step, hi = lo + t_step;    // splitter positions on the axis stream
-                        T vstart = 0;
-                        if (t_axis == 0) { if (hi < t_la) vend = rl[hi]; if (q) vstart = rl[lo]; }
-                        else if (t_axis == 1) { if (hi < t_la) vend = rt[hi]; if (q) vstart = rt[lo]; }
-                        else {
-                            uint32_t acc = 0;
-                            for (uint32_t i = 0; i < t_ic; i++) {
-                                const T left = scr[t_ib + 2 * i]; const uint32_t len = (uint32_t)scr[t_ib + 2 * i + 1];
-                                if (q && lo >= acc && lo < acc + len) vstart = left + (T)(lo - acc);
-                                if (hi >= acc && hi < acc + len) vend = left + (T)(hi - acc);
-                                acc += len;
-                            }
-                        }
-                        BVG_T1(2, tq2);
-                        const uint32_t tq3 = BVG_T0();
-                        uint32_t kept = 0, cnti = 0;
-                        if (q) {                                              // seek the mask to the first list position >= vstart
-                            const uint32_t p = t_axis == 0 ? lo : lds_lower_bound(rl, t_rlen, vstart);
-                            for (;;) {
-                                if (rpos >= p) break;
-                                if (keep == kInf || rpos + keep > p) { kept += p - rpos; if (keep != kInf) keep -= p - rpos; rpos = p; break; }
-                                kept += keep; rpos += keep;
-                                if (bi >= t_bc) { rpos = t_rlen; break; }
-                                rpos += (uint32_t)scr[t_sb + bi]; bi++;
-                                if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; }
-                            }
-                            rsi = t_axis == 1 ? lo : lds_lower_bound(rt, t_nres, vstart);
-                        }
-                        for (uint32_t i = 0; i < t_ic; i++) {                 // seek the intervals
-                            const T left = scr[t_ib + 2 * i]; const uint32_t len = (uint32_t)scr[t_ib + 2 * i + 1];
-                            if ((T)(left + len) > vstart) {
-                                const uint32_t off = vstart > left ? (uint32_t)(vstart - left) : 0u;
-                                cnti += off; ivcur = left + (T)off; ivrem = len - off; ivi = i + 1;
-                                break;
-                            }
-                            cnti += len;
-                        }
-                        j0 = kept + cnti + rsi; j = j0;
-                        if (rsi < t_nres) rhead = rt[rsi];
-                        BVG_T1(3, tq3);
-                    }
-                    const uint32_t tq4 = BVG_T0();
-                    cnt_pass++; cnt_tasks += (uint32_t)__popcll(ballot(tl)); cnt_seek += ballot(tl && q) ? 1u : 0u;
-                    // `vend` doubles as the task's state: 0 (nothing is below it) for idle lanes and finished tasks
-                    if (!tl || j >= t_d || (a.dbg & 128u)) vend = 0;
-                    for (;;) {
-                        const bool cneed = rpos < t_rlen;
-                        const T c = cneed ? rl[rpos] : sentinel<T>();
-                        const T iv = ivrem ? ivcur : sentinel<T>();
-                        T m = c < iv ? c : iv; m = m < rhead ? m : rhead;         // MergedLongIterator.java:63-92, three-way
-                        const bool emit = m < vend;                               // at vend the next task (or nothing) starts
-                        if (!ballot(emit)) break;
-                        cnt_iter++;
-                        if (emit) {
-                            if (t_stored) out[j] = m;
-                            j++;
-                            if (j >= t_d) vend = 0;
-                            if (!MAT && t_rep) blk_chk += mix_node<T>(t_k0, t_k1, m, nb_lo, nbz);
-                            if (cneed && c == m) {                            // MaskedLongIterator.java:81-100
-                                rpos++;
-                                if (--keep == 0) {
-                                    if (bi >= t_bc) rpos = t_rlen;
-                                    else { rpos += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) keep = kInf; else { keep = (uint32_t)scr[t_sb + bi]; bi++; } }
+                        const uint32_t t = p - ri - ie;                       // rank of the next copied element among the kept ones
+                        if (t_rlen) {                                         // MaskedLongIterator.java:73-100: the t-th kept position
+                            if (t_bc == 0) qcur = t;
+                            else {
+                                uint32_t pos = 0, kb = 0; bi = 0;
+                                for (;;) {
+                                    const uint32_t kl = (uint32_t)scr[t_sb + bi];
+                                    if (t < kb + kl) { qcur = pos + (t - kb); krem = kb + kl - t; bi++; break; }
+                                    kb += kl; pos += kl; bi++;
+                                    if (bi >= t_bc) { qcur = t_rlen; break; }             // an odd number of blocks: nothing is kept behind the last
+                                    pos += (uint32_t)scr[t_sb + bi]; bi++;
+                                    if (bi >= t_bc) { qcur = pos + (t - kb); break; }     // an even number: the tail is kept
                                 }
                             }
-                            if (ivrem && iv == m) {                           // LongIntervalSequenceIterator.java:71-78
-                                ivcur++;
-                                if (--ivrem == 0 && ivi < t_ic) { ivcur = scr[t_ib + 2 * ivi]; ivrem = (uint32_t)scr[t_ib + 2 * ivi + 1]; ivi++; }
-                            }
-                            if (rsi < t_nres && rhead == m) { rsi++; rhead = rsi < t_nres ? rt[rsi] : sentinel<T>(); }
                         }
                     }
-                    emitted += j - j0;
+                    BVG_T1(2, tq2);
+                    const uint32_t tq4 = BVG_T0();
+                    cnt_pass++; cnt_tasks += (uint32_t)__popcll(ballot(tl));
+                    if (a.dbg & 128u) pstop = p;
+                    const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
+                    for (;;) {
+                        const bool todo = p < pstop;
+                        if (!ballot(todo)) break;
+                        cnt_iter++;
+                        if (todo) {
+                            if (p == rnext) { ri++; rnext = (uint32_t)rt[ri]; }           // a residual: placed by Z1
+                            else {
+                                const uint32_t io = p - ivpos;
+                                const bool ii = io < ivlen;                               // LongIntervalSequenceIterator.java:71-78
+                                const T cv = rl[qcur < rlast ? qcur : rlast];
+                                const T v = ii ? (T)(ivleft + (T)io) : cv;
+                                if (t_stored) out[p] = v;
+                                if (!MAT && t_rep) blk_chk += mix_node<T>(t_k0, t_k1, v, nb_lo, nbz);
+                                if (ii) {
+                                    if (io + 1u == ivlen) {
+                                        ivk++; ivpos = kInf; ivlen = 0;
+                                        if (ivk < t_ic) { const T pk = scr[t_ib + 2 * ivk + 1]; ivlen = (uint32_t)(pk & HM); ivpos = (uint32_t)(pk >> HS); ivleft = scr[t_ib + 2 * ivk]; }
+                                    }
+                                } else {
+                                    qcur++;
+                                    if (--krem == 0) {                                    // MaskedLongIterator.java:81-100
+                                        if (bi >= t_bc) { qcur = t_rlen; krem = kInf; }
+                                        else { qcur += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) krem = kInf; else { krem = (uint32_t)scr[t_sb + bi]; bi++; } }
+                                    }
+                                }
+                            }
+                            p++;
+                        }
+                    }
                     __syncthreads();
                     BVG_T1(4, tq4);
                 }
             }
-            // every list must come out with exactly d entries; anything else (duplicates across the streams, a
-            // malformed record) is left to the generic kernel, which follows the reference's iterators literally
             if (by_tasks) {
-                if (wave_sum32(emitted) != rowW && !(a.dbg & 128u)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
+                if (ballot(zbad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
                 if (rep) { blk_arcs += d; blk_nodes += 1; }
             }
         }
