@@ -373,6 +373,17 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     }
     if (getenv("BVG_STAGE")) a.lds_stage_words = (uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u;
 
+    // Workgroup variant of the row kernel (several wavefronts share one pool): scan mode, default codings, 32-bit successors
+    int wg_nw = 0;
+    {
+        const Codings& c = a.cod;
+        const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
+        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_nw = 4;
+        if (getenv("BVG_WG")) { const int w = atoi(getenv("BVG_WG")); wg_nw = (wg_nw && (w == 2 || w == 4)) ? w : 0; }
+    }
+    auto launch_rows_any = [&](const DecodeArgs& aa, uint32_t nb, hipStream_t st) {
+        if (wg_nw) launch_rows_wg_decode(aa, nb, wg_nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
+    };
     uint32_t launches = 0, slow_blocks = 0;
     bool predicted_run = false;                        // cascade outcomes of a predicted run are remembered in g->pred
     double kernel_ms = 0;
@@ -416,7 +427,15 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const bool task = a.emit_tasks != 0;                          // task emission parks the row's residuals beside the lists
             uint64_t pool = ((uint64_t)(avg * (task ? 52.0 : 48.0)) + 255) & ~255ull;   // ~a row of lists (rows shrink when they do not fit)
             pool = std::min<uint64_t>(std::max<uint64_t>(pool, 1024), wide ? 4096 : 8192);
-            if (task) {
+            if (wg_nw) {
+                // workgroups per CU are bounded by registers (wavefronts per SIMD): give each the LDS share of that count
+                uint64_t wgs = wg_nw == 4 ? 5 : 8;
+                if (getenv("BVG_WG_BLOCKS")) wgs = std::max<uint64_t>(1, strtoull(getenv("BVG_WG_BLOCKS"), nullptr, 10));
+                const uint64_t share = ((160 * 1024) / wgs) & ~255ull, fixed = (uint64_t)a.lds_stage_words * 4 + rows_wg_static_lds(wg_nw) + 256;
+                const uint64_t fit = share > fixed ? ((share - fixed) / esz) * 8 / 9 : 1024;      // pool + pool/8 of scratch
+                pool = std::min<uint64_t>(std::max<uint64_t>(pool, fit & ~63ull), 12288);
+                pool = std::max<uint64_t>(pool, 1024);
+            } else if (task) {
                 // resident waves per CU step down with the LDS footprint: take every byte of the step the pool lands on
                 const uint64_t lds_cu = 160 * 1024, fixed = (uint64_t)a.lds_stage_words * 4 + 1536 + 256;   // window + static arrays (+ slack)
                 auto foot = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed + 1023) & ~1023ull; };
@@ -471,7 +490,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0;
             if (pd.count[5]) {
                 gpool_elems = 1ull << 16; while (gpool_elems < pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(pd.count[5], 256);
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(pd.count[5], getenv("BVG_GBATCH") ? (uint32_t)atoi(getenv("BVG_GBATCH")) : 1024u);
                 const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
                 if (bytes > g->giant_ws_bytes) {
                     if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
@@ -497,10 +516,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (!pd.count[c]) continue;
                 DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_rows_decode(ac, pd.count[c], wide, materialise, g->side[c]);   // own stream: the classes overlap each other
+                launch_rows_any(ac, pd.count[c], g->side[getenv("BVG_SIDE6") ? c : 1 + (c & 1)]);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
                 launches++;
             }
-            if (pd.count[0]) { launch_rows_decode(a0, pd.count[0], wide, materialise, g->stream); launches++; }
+            if (pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
             HIPCHK(hipStreamSynchronize(g->stream));
@@ -519,7 +538,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         } else {
         r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
                                               else if (legacy) launch_decode(a, nblocks, wide, materialise, false, g->stream);
-                                              else launch_rows_decode(a, nblocks, wide, materialise, g->stream); });
+                                              else launch_rows_any(a, nblocks, g->stream); });
         if (r) return r;
         launches++;
         r = fetch_failures(work); if (r) return r;
@@ -547,7 +566,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             r = upload_work(); if (r) return r;
             a.lds_pool_elems = classes[c]; a.lds_scr_elems = std::max<uint32_t>(1024, classes[c] / 4); a.lds_stage_words = 1024;
             const uint32_t nb = (uint32_t)work.size();
-            r = timed("tier1 (big LDS)", nb, [&] { if (legacy) launch_decode(a, nb, wide, materialise, false, g->stream); else launch_rows_decode(a, nb, wide, materialise, g->stream); });
+            r = timed("tier1 (big LDS)", nb, [&] { if (legacy) launch_decode(a, nb, wide, materialise, false, g->stream); else launch_rows_any(a, nb, g->stream); });
             if (r) return r;
             launches++;
             std::vector<uint32_t> again;
@@ -600,7 +619,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
 
     unsigned long long acc[20];
     HIPCHK(hipMemcpy(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost));
-    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: merge steps %llu, task passes %llu (with seeks %llu), rows %llu, tasks %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7]);
+    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: merge steps %llu, task passes %llu (with seeks %llu), rows %llu, tasks %llu, residual steps %llu (lanes %llu)\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[19] & 0xFFFFFFFFull, acc[19] >> 32);
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
         fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6);

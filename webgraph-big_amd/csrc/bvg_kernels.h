@@ -56,6 +56,10 @@ struct DecodeArgs {
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
 // the lean LDS-resident row kernel (bvg_rows.hip): tiers 0 and 1
 void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
+// the same with one workgroup of nw (2 or 4) wavefronts per block sharing the pool (bvg_rows_wg.hip): scan mode, default
+// codings, 32-bit successors only
+void launch_rows_wg_decode(const DecodeArgs& a, uint32_t nblocks, int nw, hipStream_t s);
+size_t rows_wg_static_lds(int nw);
 // the streaming data-flow kernel (bvg_stream.hip): fast path; lds_pool_elems must be a power of two
 void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 

@@ -19,8 +19,7 @@
 // Whatever does not fit (a list larger than the pool, a record larger than the window, a code
 // longer than 64 bits) makes the block fail over to the next tier (bigger LDS, then the generic
 // global-memory kernel in bvg_kernels.hip).
-#include "bvg_kernels.h"
-#include "bvg_lds_codes.h"
+#include "bvg_rows_common.h"
 
 #ifndef BVG_ROWS_WAVES
 #define BVG_ROWS_WAVES 6
@@ -33,61 +32,7 @@ namespace bvg {
 
 namespace {
 
-constexpr uint32_t kInf = 0xFFFFFFFFu;
-constexpr uint32_t LIN = 0xFFFFFFFFu;          // linear window: no index mask
-constexpr uint32_t RM = kRing - 1;
-constexpr uint32_t kMinTask = 4;               // shortest task (outputs) worth a seek
-
-template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
-
-__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) { return wave_incl_scan(v); }
-
-// lower bound in a sorted LDS array: number of elements < v
-template <typename T> __device__ __forceinline__ uint32_t lds_lower_bound(const T* arr, uint32_t n, T v) {
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (arr[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-
-// one residual gap at bit `rel` of the staged window (BVG:788-795): zeta_k from a 32-bit window when it fits, else the
-// 64-bit decoders; returns the code length, 0 = does not fit 64 bits (fail over)
-template <bool GEN> __device__ __forceinline__ uint32_t read_residual(const uint32_t* stage, uint32_t rel, bool zfast, uint32_t zk, int coding, uint64_t& val) {
-    uint32_t len = 0; val = 0;
-    if (zfast) {
-        const uint32_t w = win32<LIN>(stage, rel);
-        const uint32_t z = w ? (uint32_t)__builtin_clz(w) : 32u;
-        const uint32_t nbz = z * zk + zk - 1, zt = z + 1 + nbz;
-        if (zt < 32) {
-            const uint32_t tt = (w << (z + 1)) >> (32u - nbz);
-            const uint32_t leftv = 1u << (z * zk);
-            if (tt < leftv) { val = tt + leftv - 1u; len = zt; }
-            else { val = ((tt << 1) | ((w >> (31u - zt)) & 1u)) - 1u; len = zt + 1; }
-        }
-    }
-    if (len == 0) {
-        const uint64_t w = win64<LIN>(stage, rel);
-        len = GEN ? decode_generic_w(w, coding, zk, &val) : zeta64(w, zk, val);
-    }
-    return len;
-}
-
-// checksum term of successor m of a node whose key is (kA, k1), kA = k0 + lo(node_base) + hi(node_base) * 0x9E3779B1: the
-// same value as mix_keyed(k0, k1, m + node_base) with the 64-bit add folded into the key (a carry adds the constant once)
-template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t kA, uint32_t k1, T m, uint32_t nbl, bool nbz) {
-    if (sizeof(T) == 8) {
-        const uint64_t m64 = (uint64_t)m; const uint32_t ml = (uint32_t)m64, mh = (uint32_t)(m64 >> 32);
-        uint32_t a_ = ml + kA + mh * 0x9E3779B1u;
-        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
-        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
-        return (uint64_t)b * (uint64_t)k1;
-    } else {
-        const uint32_t ml = (uint32_t)m;
-        uint32_t a_ = ml + kA;
-        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
-        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
-        return (uint64_t)b * (uint64_t)k1;
-    }
-}
+using namespace rows;
 
 template <typename T, bool MAT, bool GEN, bool TASK>
 __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) rows_kernel(DecodeArgs a) {

@@ -1,0 +1,75 @@
+// bvg_rows_common.h — helpers shared by the row kernels (bvg_rows.hip: one wavefront per block; bvg_rows_wg.hip: one
+// workgroup of several wavefronts per block).
+#pragma once
+#include "bvg_kernels.h"
+#include "bvg_lds_codes.h"
+
+namespace bvg {
+namespace rows {
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t LIN = 0xFFFFFFFFu;          // linear window: no index mask
+constexpr uint32_t RM = kRing - 1;
+constexpr uint32_t kMinTask = 4;               // shortest task (outputs) worth a seek
+
+template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) { return wave_incl_scan(v); }
+
+// lower bound in a sorted LDS array: number of elements < v
+template <typename T> __device__ __forceinline__ uint32_t lds_lower_bound(const T* arr, uint32_t n, T v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (arr[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// one residual gap at bit `rel` of the staged window (BVG:788-795): zeta_k from a 32-bit window when it fits, else the
+// 64-bit decoders; returns the code length, 0 = does not fit 64 bits (fail over)
+template <bool GEN> __device__ __forceinline__ uint32_t read_residual(const uint32_t* stage, uint32_t rel, bool zfast, uint32_t zk, int coding, uint64_t& val) {
+    uint32_t len = 0; val = 0;
+    if (zfast) {
+        const uint32_t w = win32<LIN>(stage, rel);
+        const uint32_t z = w ? (uint32_t)__builtin_clz(w) : 32u;
+        const uint32_t nbz = z * zk + zk - 1, zt = z + 1 + nbz;
+        if (zt < 32) {
+            const uint32_t tt = (w << (z + 1)) >> (32u - nbz);
+            const uint32_t leftv = 1u << (z * zk);
+            if (tt < leftv) { val = tt + leftv - 1u; len = zt; }
+            else { val = ((tt << 1) | ((w >> (31u - zt)) & 1u)) - 1u; len = zt + 1; }
+        }
+    }
+    if (len == 0) {
+        const uint64_t w = win64<LIN>(stage, rel);
+        len = GEN ? decode_generic_w(w, coding, zk, &val) : zeta64(w, zk, val);
+    }
+    return len;
+}
+
+// checksum term of successor m of a node whose key is (kA, k1), kA = k0 + lo(node_base) + hi(node_base) * 0x9E3779B1: the
+// same value as mix_keyed(k0, k1, m + node_base) with the 64-bit add folded into the key (a carry adds the constant once)
+template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t kA, uint32_t k1, T m, uint32_t nbl, bool nbz) {
+    if (sizeof(T) == 8) {
+        const uint64_t m64 = (uint64_t)m; const uint32_t ml = (uint32_t)m64, mh = (uint32_t)(m64 >> 32);
+        uint32_t a_ = ml + kA + mh * 0x9E3779B1u;
+        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
+        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
+        return (uint64_t)b * (uint64_t)k1;
+    } else {
+        const uint32_t ml = (uint32_t)m;
+        uint32_t a_ = ml + kA;
+        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
+        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
+        return (uint64_t)b * (uint64_t)k1;
+    }
+}
+
+// ordering point for LDS traffic inside ONE wavefront (its lanes run in lock step and its LDS operations complete in
+// order): only the compiler has to be kept from moving accesses across it
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace rows
+}  // namespace bvg
