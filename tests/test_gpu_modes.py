@@ -3,7 +3,8 @@
 The default policy picks the row-kernel variant per graph and the emission form per row, so the ordinary parity tests do not
 reach every combination on their small graphs; here the debug switches (BVG_EMIT, BVG_DBG 16/32, BVG_NOSKIP — read at
 every call) pin each one: level-synchronous tasks on every row, the pipelined loop inside the task variant, the pipelined
-variant alone, and all of them with and without the skip index."""
+variant alone, all of them with and without the skip index, and the experimental workgroup variant of the row kernel (BVG_WG:
+several wavefronts share one list pool) in scan mode."""
 import numpy as np
 import pytest
 
@@ -16,12 +17,15 @@ MODES = {
     "pipelined_variant": dict(BVG_EMIT="0"),
     "tasks_no_skip_index": dict(BVG_EMIT="1", BVG_DBG="16", BVG_NOSKIP="1"),
     "pipelined_no_skip_index": dict(BVG_EMIT="0", BVG_NOSKIP="1"),
+    "workgroup_2_wavefronts": dict(BVG_EMIT="1", BVG_WG="2"),
+    "workgroup_4_wavefronts": dict(BVG_EMIT="1", BVG_WG="4"),
+    "workgroup_2_no_skip_index": dict(BVG_EMIT="1", BVG_WG="2", BVG_NOSKIP="1"),
 }
 
 
 @pytest.fixture(params=sorted(MODES))
 def mode(request, monkeypatch):
-    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP"):
+    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_WG"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[request.param].items():
         monkeypatch.setenv(k, v)

@@ -378,8 +378,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     {
         const Codings& c = a.cod;
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_nw = 4;
-        if (getenv("BVG_WG")) { const int w = atoi(getenv("BVG_WG")); wg_nw = (wg_nw && (w == 2 || w == 4)) ? w : 0; }
+        // experimental (BVG_WG=2|4; measured: +4 % at 2 wavefronts on the eu shape, slower on sparse graphs and at 4): off by default
+        if (getenv("BVG_WG") && !materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) {
+            const int w = atoi(getenv("BVG_WG")); wg_nw = (w == 2 || w == 4) ? w : 0;
+        }
     }
     auto launch_rows_any = [&](const DecodeArgs& aa, uint32_t nb, hipStream_t st) {
         if (wg_nw) launch_rows_wg_decode(aa, nb, wg_nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
