@@ -170,7 +170,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
     }
     HIPCHK(hipEventCreate(&g->ev0));
     HIPCHK(hipEventCreate(&g->ev1));
-    HIPCHK(hipMalloc(&g->d_acc, 20 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&g->d_acc, (size_t)kAccStripes * kAccStride * sizeof(unsigned long long)));   // stripe 0 also holds the debug counters [4..19]
     g->fail_cap = 1u << 16;
     HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     *out = g;
@@ -336,7 +336,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         g->fail_cap = nblocks;
         HIPCHK(hipMalloc(&g->d_fail, (2 * (size_t)g->fail_cap + 1) * sizeof(uint32_t)));
     }
-    HIPCHK(hipMemsetAsync(g->d_acc, 0, 20 * sizeof(unsigned long long), g->stream));
+    HIPCHK(hipMemsetAsync(g->d_acc, 0, (size_t)kAccStripes * kAccStride * sizeof(unsigned long long), g->stream));
     HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
 
     DecodeArgs a{};
@@ -345,7 +345,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.blk_first = batch ? batch->d_first : pl.d_first; a.blk_halo = batch ? batch->d_halo : pl.d_halo; a.blk_mask = batch ? batch->d_mask : pl.d_mask;
     a.work_list = nullptr; a.blk_lo = lo; a.batch = batch ? 1u : 0u;
     a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
-    a.node_base = g->node_base; a.acc = g->d_acc; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
+    a.node_base = g->node_base; a.acc = g->d_acc; a.acc_mask = getenv("BVG_NOSTRIPE") ? 0u : kAccStripes - 1; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
     a.dbg = getenv("BVG_DBG") ? (uint32_t)strtoul(getenv("BVG_DBG"), nullptr, 10) : 0;
     // Row-kernel variant: splitting lists into tasks pays on dense or reference-free graphs; sparse graphs with reference
@@ -620,7 +620,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (d_work) (void)hipFree(d_work);
 
     unsigned long long acc[20];
-    HIPCHK(hipMemcpy(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost));
+    launch_reduce_acc(g->d_acc, kAccStripes, g->stream);
+    HIPCHK(hipMemcpyAsync(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
     if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: merge steps %llu, task passes %llu (with seeks %llu), rows %llu, tasks %llu, residual steps %llu (lanes %llu)\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[19] & 0xFFFFFFFFull, acc[19] >> 32);
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);

@@ -9,6 +9,7 @@ namespace bvg {
 
 // LDS geometry of the fast (one wavefront per node block) decode kernel.
 constexpr uint32_t kSkipMin = 48, kSkipEvery = 32;   // residual skip index granularity
+constexpr uint32_t kAccStripes = 2048, kAccStride = 32;   // result stripes (power of two), 256 bytes apart (stripe 0 also carries 16 debug counters)
 constexpr int kRing = 128;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
 constexpr int kMaxWindow = 64;       // larger windows take the slow path only if a block needs it; beyond: unsupported
 constexpr int kMaxHalo = 64;         // halo nodes a block may need from before its first node (one row)
@@ -27,7 +28,9 @@ struct DecodeArgs {
     int window, min_interval;
     Codings cod;
     uint64_t node_base;
-    unsigned long long* acc;            // [0] arcs [1] chk [2] nodes [3] error bits
+    unsigned long long* acc;            // [0] arcs [1] chk [2] nodes [3] error bits (+ debug counters) of stripe 0
+    uint32_t acc_mask;                  // the block results are striped over acc_mask+1 copies of those four words, kAccStride words apart
+                                        // (one address for every block costs ~12 ns per atomic: 9 ms per GiB of 4 KiB blocks), summed by reduce_acc
     // materialise
     const uint64_t* cum;                // exclusive prefix of outdegrees for nodes [from,to], or nullptr
     int64_t* succ; int32_t* outdeg;
@@ -63,6 +66,8 @@ size_t rows_wg_static_lds(int nw);
 // the streaming data-flow kernel (bvg_stream.hip): fast path; lds_pool_elems must be a power of two
 void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 
+// sums the result stripes into stripe 0 (one workgroup)
+void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);
 // thread per node: outdegree (BVG:821-842)
 void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,
                        int outdegree_coding, int32_t* out, unsigned long long* total, hipStream_t s);

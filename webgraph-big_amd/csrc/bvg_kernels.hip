@@ -307,10 +307,11 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     }
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
-        atomicAdd(&a.acc[0], (unsigned long long)blk_arcs);
-        atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
-        atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
-        if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+        unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
+        atomicAdd(&accs[0], (unsigned long long)blk_arcs);
+        atomicAdd(&accs[1], (unsigned long long)blk_chk);
+        atomicAdd(&accs[2], (unsigned long long)blk_nodes);
+        if (err) atomicOr(&accs[3], (unsigned long long)err);
     }
 }
 
@@ -542,6 +543,30 @@ void launch_exclusive_scan(const int32_t* in, uint64_t* out, int64_t n, uint64_t
     hipLaunchKernelGGL(scan_partials, dim3((unsigned)parts), dim3(256), 0, s, in, n, tmp);
     hipLaunchKernelGGL(scan_partials_serial, dim3(1), dim3(64), 0, s, tmp, parts);
     hipLaunchKernelGGL(scan_final, dim3((unsigned)parts), dim3(256), 0, s, in, n, tmp, out);
+}
+
+// result stripes -> stripe 0: sums of the three counters, OR of the error bits
+__global__ void __launch_bounds__(256) reduce_acc_kernel(unsigned long long* acc, uint32_t stripes) {
+    __shared__ unsigned long long part[4][4];
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (uint32_t s = threadIdx.x; s < stripes; s += 256) {
+        const unsigned long long* p = acc + (size_t)s * kAccStride;
+        v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] |= p[3];
+    }
+    v[0] = wave_sum64(v[0]); v[1] = wave_sum64(v[1]); v[2] = wave_sum64(v[2]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[3] |= __shfl_xor(v[3], o, 64);
+    if ((threadIdx.x & 63u) == 0) for (int i = 0; i < 4; i++) part[threadIdx.x >> 6][i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc[0] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+        acc[1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+        acc[2] = part[0][2] + part[1][2] + part[2][2] + part[3][2];
+        acc[3] = part[0][3] | part[1][3] | part[2][3] | part[3][3];
+    }
+}
+void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_acc_kernel, dim3(1), dim3(256), 0, s, acc, stripes);
 }
 
 void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s) {

@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         // Steps A..D with two wave-uniform points where the scratch area (copy blocks, then intervals) is
         // allocated by prefix sums; lanes whose entries do not fit are cut from the row (k shrinks) and
         // their nodes are simply parsed again at the head of the next row.
-        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0, di = 0;
+        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
         int64_t extra = d;
         bool malf = false;                                                   // counts that contradict each other (position tasks need them exact)
         const bool parse = needed && lane < k && d > 0 && !(a.dbg & 4);
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
                     const int64_t len = (int64_t)v2 + minint;
                     prev = leftv + len;
-                    extra -= len; di += (uint32_t)len;
+                    extra -= len;
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
                 if (extra < 0) { err |= ERR_MALFORMED; extra = 0; malf = true; }
@@ -716,10 +716,11 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
         if (a.skip_mode == 1 && a.skip_cnt) a.skip_cnt[bid] = sk_run;
-        atomicAdd(&a.acc[0], (unsigned long long)blk_arcs);
-        atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
-        atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
-        if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+        unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
+        atomicAdd(&accs[0], (unsigned long long)blk_arcs);
+        atomicAdd(&accs[1], (unsigned long long)blk_chk);
+        atomicAdd(&accs[2], (unsigned long long)blk_nodes);
+        if (err) atomicOr(&accs[3], (unsigned long long)err);
         if (a.dbg & 64u) {
             atomicAdd(&a.acc[4], (unsigned long long)cnt_iter); atomicAdd(&a.acc[5], (unsigned long long)cnt_pass); atomicAdd(&a.acc[6], (unsigned long long)cnt_rows);
             atomicAdd(&a.acc[7], (unsigned long long)cnt_tasks); atomicAdd(&a.acc[8], (unsigned long long)cnt_seek);

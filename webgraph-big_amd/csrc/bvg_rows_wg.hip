@@ -554,10 +554,11 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
     err = wave_or32(err);
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
-        if (blk_arcs) atomicAdd(&a.acc[0], (unsigned long long)blk_arcs);
-        if (blk_chk) atomicAdd(&a.acc[1], (unsigned long long)blk_chk);
-        if (blk_nodes) atomicAdd(&a.acc[2], (unsigned long long)blk_nodes);
-        if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+        unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
+        if (blk_arcs) atomicAdd(&accs[0], (unsigned long long)blk_arcs);
+        if (blk_chk) atomicAdd(&accs[1], (unsigned long long)blk_chk);
+        if (blk_nodes) atomicAdd(&accs[2], (unsigned long long)blk_nodes);
+        if (err) atomicOr(&accs[3], (unsigned long long)err);
     }
 }
 

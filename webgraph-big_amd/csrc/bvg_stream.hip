@@ -406,10 +406,11 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
     }
     acc_arcs = wave_sum64(acc_arcs); acc_chk = wave_sum64(acc_chk); acc_nodes = wave_sum64(acc_nodes);
     if (lane == 0) {
-        atomicAdd(&a.acc[0], (unsigned long long)acc_arcs);
-        atomicAdd(&a.acc[1], (unsigned long long)acc_chk);
-        atomicAdd(&a.acc[2], (unsigned long long)acc_nodes);
-        if (err) atomicOr(&a.acc[3], (unsigned long long)err);
+        unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
+        atomicAdd(&accs[0], (unsigned long long)acc_arcs);
+        atomicAdd(&accs[1], (unsigned long long)acc_chk);
+        atomicAdd(&accs[2], (unsigned long long)acc_nodes);
+        if (err) atomicOr(&accs[3], (unsigned long long)err);
     }
 }
 
