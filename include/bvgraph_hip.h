@@ -141,6 +141,30 @@ int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);
 int bvg_transpose(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint64_t tsucc_cap, uint64_t* n_arcs);
 int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t tsucc_cap, uint64_t* n_arcs);
 
+/* ---- arc labels stored as a bit stream (labelling/BitStreamArcLabelledImmutableGraph.java) ----
+ * basename.labels holds, node after node, the labels of the node's arcs in successor order (:75-84); basename.labeloffsets the
+ * gamma-coded bit lengths of those runs after a leading gamma(0) (store(), :655-680).  The node iterator reads `outdegree`
+ * labels per node (:565-582).  Built for the scalar label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64) and
+ * FixedWidthIntLabel (FixedWidthIntLabel.java:70-73); list labels return BVG_E_UNSUPPORTED. */
+enum { BVG_LABEL_GAMMA_INT = 1, BVG_LABEL_FIXED_INT = 2 };
+typedef struct bvg_labels bvg_labels;
+/* Label.toSpec() text, e.g. "it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,10)" -> kind, width. */
+int bvg_labels_parse_spec(const char* spec, int* kind, int* width);
+/* label_offsets: nodes+1 bit positions into the label stream (decode basename.labeloffsets with bvg_decode_offsets(.., BVG_GAMMA, ..)). */
+int bvg_labels_open_mem(int kind, int width, int64_t nodes, const uint8_t* stream, uint64_t nbytes, const uint64_t* label_offsets, int device, bvg_labels** out);
+/* BitStreamArcLabelledImmutableGraph.load (:378-484): reads basename.{properties,labels,labeloffsets}; `underlying` receives the
+ * basename of the underlying graph (property underlyinggraph, resolved against the property file), to be opened with bvg_open.
+ * nodes = numNodes() of that graph. */
+int bvg_labels_open(const char* basename, int64_t nodes, int device, bvg_labels** out, char* underlying, size_t underlying_cap);
+void bvg_labels_close(bvg_labels* l);
+int bvg_labels_info(const bvg_labels* l, int* kind, int* width, int64_t* nodes, uint64_t* stream_bytes);
+/* Labels of the arcs of nodes [from,to) in the order bvg_decode_range lists the successors; outdeg[to-from] as returned by it.
+ * *n_labels = sum of the outdegrees; BVG_E_CAPACITY if cap is smaller; BVG_E_EOF if a node's run does not end at the next offset
+ * (the outdegrees do not belong to this label stream). */
+int bvg_labels_decode_range(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, int32_t* labels, uint64_t cap, uint64_t* n_labels);
+/* Same, outdegrees (int32) and labels (int32) in device memory: chains with bvg_decode_range_dev without leaving HBM. */
+int bvg_labels_decode_range_dev(bvg_labels* l, int64_t from, int64_t to, const void* d_outdeg, void* d_labels, uint64_t cap, uint64_t* n_labels);
+
 /* ---- synthetic-workload helper (bench only): K back-to-back copies of the graph ----
  * BV records are translation invariant (every value is coded relative to the node id, Appendix A.3
  * of SURVEY.md), so the concatenation of K copies of the bit stream is a valid BVGraph with K*nodes
