@@ -75,6 +75,8 @@ def lib():
         L.bvgo_read_zeta.argtypes = [C.POINTER(Bits), C.c_int]; L.bvgo_read_zeta.restype = u64
         L.bvgo_read_golomb.argtypes = [C.POINTER(Bits), u64]; L.bvgo_read_golomb.restype = u64
         L.bvgo_nat2int.argtypes = [u64]; L.bvgo_nat2int.restype = i64
+        L.bvgo_parse_label_spec.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.bvgo_labels_decode.argtypes = [C.c_int, C.c_int, vp, u64, vp, i64, i64, i64, vp, vp, u64, C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -226,3 +228,27 @@ class NodeIterator:
 
 def mix(x, y):
     return int(lib().bvgo_mix(x, y))
+
+
+LABEL_GAMMA_INT, LABEL_FIXED_INT = 1, 2
+
+
+def parse_label_spec(spec):
+    """Label.toSpec() text -> (kind, width)."""
+    k, w = C.c_int(), C.c_int()
+    _chk(lib().bvgo_parse_label_spec(spec.encode() if isinstance(spec, str) else spec, C.byref(k), C.byref(w)))
+    return k.value, w.value
+
+
+def labels_decode(kind, width, stream, loffsets, frm, to, outdeg):
+    """Labels of the arcs of nodes [frm,to) (BitStreamArcLabelledImmutableGraph.java:565-582): int32 array."""
+    stream = np.ascontiguousarray(np.frombuffer(bytes(stream), dtype=np.uint8))
+    pad = np.concatenate([stream, np.zeros(16, np.uint8)])
+    lo = np.ascontiguousarray(loffsets, dtype=np.uint64)
+    deg = np.ascontiguousarray(outdeg, dtype=np.int32)
+    total = int(deg.sum())
+    out = np.empty(max(total, 1), dtype=np.int32)
+    n = C.c_uint64()
+    _chk(lib().bvgo_labels_decode(kind, width, pad.ctypes.data, len(stream), lo.ctypes.data, len(lo) - 1, frm, to,
+                                  deg.ctypes.data if len(deg) else None, out.ctypes.data, total, C.byref(n)))
+    return out[:total]

@@ -1,0 +1,113 @@
+"""Arc labels stored as a bit stream (labelling/BitStreamArcLabelledImmutableGraph.java).
+
+CPU part: the oracle's restatement of the label layout against hand-written bit patterns (gamma is the code the cnr-2000 golden
+pins), the tooling writer against the oracle, the label-spec parser of both the oracle and the C ABI.  GPU part: the device
+decode through the C ABI against the oracle on labelled synthetic graphs, from memory and from files, with the edge cases of
+the reference's own labelled tests (test/.../labelling/BitStreamArcLabelledGraphTest.java: empty lists, width 0..32, every
+start node)."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _labelled(tools, n, seed, kind, width, synth=None):
+    st = tools.synth_store(n, seed=seed, synth=synth, threads=2)
+    off, adj = tools.synth_adjacency(n, seed=seed, synth=synth)
+    rng = np.random.default_rng(seed)
+    m = int(off[-1])
+    if kind == 1:
+        vals = rng.geometric(0.02, size=m).astype(np.int64) - 1
+        vals[rng.random(m) < 0.01] = 2 ** 31 - 2                              # the largest value readGamma() can return
+    else:
+        vals = rng.integers(0, 2 ** width if width < 32 else 2 ** 32, size=m, dtype=np.uint64).astype(np.int64)
+    vals32 = vals.astype(np.uint32).view(np.int32) if kind == 2 else vals.astype(np.int32)
+    return st, off, adj, vals32, tools.store_labels(kind, width, vals32, off)
+
+
+def test_oracle_reads_handwritten_label_streams(oracle):
+    # gamma(0)=1 gamma(1)=010 | node 1 empty | gamma(5)=00110 gamma(1000)=0000000001 111101001 gamma(7)=0001000
+    stream = bytes.fromhex("a3003e9100")
+    lo = np.array([0, 4, 4, 35], dtype=np.uint64)
+    deg = np.array([2, 0, 3], dtype=np.int32)
+    assert oracle.labels_decode(1, 0, stream, lo, 0, 3, deg).tolist() == [0, 1, 5, 1000, 7]
+    assert oracle.labels_decode(1, 0, stream, lo, 2, 3, deg[2:]).tolist() == [5, 1000, 7]           # random access (:208-229)
+    assert oracle.labels_decode(1, 0, stream, lo, 1, 2, deg[1:2]).tolist() == []
+    # FixedWidthIntLabel(FOO,10): readInt(10) per arc
+    stream = bytes.fromhex("00001017e801c0")
+    lo = np.array([0, 20, 20, 50], dtype=np.uint64)
+    assert oracle.labels_decode(2, 10, stream, lo, 0, 3, deg).tolist() == [0, 1, 5, 1000, 7]
+    with pytest.raises(oracle.OracleError):                                    # degrees that do not belong to the stream
+        oracle.labels_decode(2, 10, stream, lo, 0, 3, np.array([2, 1, 3], dtype=np.int32))
+
+
+def test_label_spec_parsers_agree(W, oracle):
+    for spec, want in (("it.unimi.dsi.big.webgraph.labelling.GammaCodedIntLabel(FOO)", (1, 0)),
+                       ("it.unimi.dsi.webgraph.labelling.FixedWidthIntLabel(FOO,10)", (2, 10)),
+                       ("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel( weight , 32 )", (2, 32))):
+        assert oracle.parse_label_spec(spec) == want and W.parse_label_spec(spec) == want
+    with pytest.raises(W.UnsupportedOperationException):
+        W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntListLabel(FOO,10)")
+    with pytest.raises(W.IOException):
+        W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,33)")
+
+
+@pytest.mark.parametrize("kind,width", [(1, 0), (2, 1), (2, 10), (2, 31), (2, 32), (2, 0)])
+def test_writer_and_oracle_round_trip(tools, oracle, kind, width):
+    st, off, adj, vals, sl = _labelled(tools, 3000, 5, kind, width)
+    deg = np.diff(off.astype(np.int64)).astype(np.int32)
+    got = oracle.labels_decode(kind, width, sl.stream, sl.offsets, 0, 3000, deg)
+    want = vals if (width or kind == 1) else np.zeros_like(vals)
+    assert np.array_equal(got, want)
+    if kind == 2:                                                              # fixedWidth() labels: every run is d * width bits
+        assert np.array_equal(np.diff(sl.offsets.astype(np.int64)), deg.astype(np.int64) * width)
+    for a, b in ((0, 1), (17, 400), (2999, 3000), (1234, 1234)):
+        assert np.array_equal(oracle.labels_decode(kind, width, sl.stream, sl.offsets, a, b, deg[a:b]), want[int(off[a]):int(off[b])])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,width", [(1, 0), (2, 1), (2, 10), (2, 32), (2, 0)])
+def test_gpu_labels_match_oracle(W, tools, oracle, kind, width):
+    n = 20000
+    st, off, adj, vals, sl = _labelled(tools, n, 9, kind, width, synth=tools.eu_like() if kind == 1 else None)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    lg = W.BitStreamArcLabelledImmutableGraph.from_memory(g, kind, width, sl.stream, sl.offsets)
+    deg, succ, lab = lg.decode_range(0, n)
+    odeg = np.diff(off.astype(np.int64)).astype(np.int32)
+    assert np.array_equal(deg, odeg) and np.array_equal(succ, adj)
+    assert np.array_equal(lab, oracle.labels_decode(kind, width, sl.stream, sl.offsets, 0, n, odeg))
+    for a, b in ((0, 1), (n - 1, n), (777, 778), (5000, 5000), (123, 9000)):   # every kind of sub-range / single node
+        d2, s2, l2 = lg.decode_range(a, b)
+        assert np.array_equal(s2, adj[int(off[a]):int(off[b])])
+        assert np.array_equal(l2, oracle.labels_decode(kind, width, sl.stream, sl.offsets, a, b, odeg[a:b]))
+    x = int(np.argmax(odeg))
+    it = lg.successors(x)                                                      # LabelledArcIterator: label() after nextLong()
+    pairs = []
+    while True:
+        s = it.next_long()
+        if s == -1:
+            break
+        pairs.append((s, it.label()))
+    want = vals if width or kind == 1 else np.zeros_like(vals)
+    assert pairs == list(zip(adj[int(off[x]):int(off[x + 1])].tolist(), want[int(off[x]):int(off[x + 1])].tolist()))
+    lg.close(); g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_labelled_graph_from_files(W, tools, oracle, tmp_path):
+    n = 5000
+    st, off, adj, vals, sl = _labelled(tools, n, 21, 1, 0)
+    st.write(str(tmp_path / "under"))
+    sl.write(str(tmp_path / "lab"), "under")
+    lg = W.BitStreamArcLabelledImmutableGraph.load(str(tmp_path / "lab"))
+    deg, succ, lab = lg.decode_range(0, n)
+    assert np.array_equal(succ, adj) and np.array_equal(lab, vals)
+    with pytest.raises(W.IllegalArgumentException):
+        lg.successors(n)
+    # outdegrees that do not belong to the label stream are rejected, nothing is returned
+    bad = deg.copy(); bad[np.argmax(deg > 0)] += 1
+    import ctypes as C
+    out = np.empty(int(bad.sum()) + 1, dtype=np.int32); cnt = C.c_uint64()
+    r = W.lib().bvg_labels_decode_range(lg._h, 0, n, bad.ctypes.data, out.ctypes.data, len(out), C.byref(cnt))
+    assert r == W.E_EOF
+    lg.close()

@@ -117,6 +117,13 @@ def lib():
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
         L.bvg_transpose.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_transpose_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_labels_parse_spec.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.bvg_labels_open_mem.argtypes = [C.c_int, C.c_int, i64, vp, u64, vp, C.c_int, pp]
+        L.bvg_labels_open.argtypes = [C.c_char_p, i64, C.c_int, pp, C.c_char_p, C.c_size_t]
+        L.bvg_labels_close.argtypes = [vp]; L.bvg_labels_close.restype = None
+        L.bvg_labels_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(u64)]
+        L.bvg_labels_decode_range.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_labels_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_tile.argtypes = [vp, i64, pp]
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
@@ -462,3 +469,100 @@ class BVGraph:
         r = ScanResult()
         _check(lib().bvg_scan(self._h, frm, to, C.byref(r)), "scan(%d,%d)" % (frm, to))
         return r.as_dict()
+
+
+LABEL_GAMMA_INT, LABEL_FIXED_INT = 1, 2
+
+
+def parse_label_spec(spec):
+    """Label.toSpec() text (e.g. "...labelling.FixedWidthIntLabel(FOO,10)") -> (kind, width)."""
+    k, w = C.c_int(), C.c_int()
+    _check(lib().bvg_labels_parse_spec(spec.encode() if isinstance(spec, str) else spec, C.byref(k), C.byref(w)), "labelspec %r" % (spec,))
+    return k.value, w.value
+
+
+class LabelledArcIterator(LazyLongIterator):
+    """ArcLabelledNodeIterator.LabelledArcIterator (labelling/ArcLabelledNodeIterator.java): successors with label()."""
+
+    def __init__(self, succ, labels):
+        LazyLongIterator.__init__(self, succ)
+        self._l = labels
+
+    def label(self):
+        """The label of the arc returned by the last next_long() (BitStreamArcLabelledImmutableGraph.java:250-252)."""
+        if self._i == 0:
+            raise IllegalStateException(_abi.E_STATE, "label() before nextLong()")
+        return int(self._l[self._i - 1])
+
+
+class BitStreamArcLabelledImmutableGraph:
+    """labelling/BitStreamArcLabelledImmutableGraph.java: an underlying BVGraph plus one int label per arc, both decoded on the
+    device (GammaCodedIntLabel / FixedWidthIntLabel)."""
+
+    def __init__(self, graph, handle, keep=()):
+        self.g = graph
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def load(cls, basename, device=0):
+        """load(basename) (:378-484): basename.properties names the underlying graph and the label class."""
+        text = open(basename + ".properties").read()
+        under = None
+        for line in text.splitlines():
+            k, _, v = line.partition("=")
+            if k.strip() == "underlyinggraph":
+                under = v.strip()
+        if under is None:
+            raise IOException(_abi.E_IO, "no underlyinggraph in %s.properties" % basename)
+        if not os.path.isabs(under):
+            under = os.path.join(os.path.dirname(basename), under)
+        g = BVGraph.load(under, device)
+        h = C.c_void_p()
+        buf = C.create_string_buffer(4096)
+        _check(lib().bvg_labels_open(os.fsencode(basename), g.num_nodes(), device, C.byref(h), buf, len(buf)), "load(%s)" % basename)
+        return cls(g, h)
+
+    @classmethod
+    def from_memory(cls, graph, kind, width, stream, label_offsets, device=0):
+        st = np.frombuffer(bytes(stream), dtype=np.uint8) if not isinstance(stream, np.ndarray) else np.ascontiguousarray(stream, dtype=np.uint8)
+        lo = np.ascontiguousarray(label_offsets, dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().bvg_labels_open_mem(kind, width, graph.num_nodes(), st.ctypes.data if len(st) else None, len(st), lo.ctypes.data, device, C.byref(h)), "labels_open_mem")
+        return cls(graph, h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bvg_labels_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_nodes(self):
+        return self.g.num_nodes()
+
+    def num_arcs(self):
+        return self.g.num_arcs()
+
+    def outdegree(self, x):
+        return self.g.outdegree(x)
+
+    def decode_range(self, frm, to):
+        """(outdeg, successors, labels) of nodes [frm,to): one batch of the labelled node iterator (:565-582)."""
+        deg, succ = self.g.decode_range(frm, to)
+        lab = np.empty(max(len(succ), 1), dtype=np.int32)
+        n = C.c_uint64()
+        d32 = np.ascontiguousarray(deg, dtype=np.int32)
+        _check(lib().bvg_labels_decode_range(self._h, frm, to, d32.ctypes.data if len(d32) else None, lab.ctypes.data, len(succ), C.byref(n)), "labels(%d,%d)" % (frm, to))
+        return deg, succ, lab[:len(succ)]
+
+    def successors(self, x):
+        """successors(x) (:208-229): a LabelledArcIterator."""
+        if x < 0 or x >= self.num_nodes():
+            raise IllegalArgumentException(_abi.E_ARG, "successors(%d)" % x)
+        _, succ, lab = self.decode_range(x, x + 1)
+        return LabelledArcIterator(succ, lab)

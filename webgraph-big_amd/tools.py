@@ -62,6 +62,7 @@ def lib():
         L.bvgt_synth_adjacency.argtypes = [C.POINTER(SynthParams), i64, u64, i64, pp, pp]
         L.bvgt_encode_offsets.argtypes = [vp, i64, C.c_int, pp, C.POINTER(u64), C.POINTER(u64)]
         L.bvgt_encode_values.argtypes = [vp, i64, C.c_int, C.c_int, pp, C.POINTER(u64)]
+        L.bvgt_store_labels.argtypes = [C.c_int, C.c_int, vp, vp, i64, pp, C.POINTER(u64), pp]
         L.bvgt_free.argtypes = [vp]
         _LIB = L
     return _LIB
@@ -169,3 +170,36 @@ def encode_values(vals, coding, k=3):
     if r:
         raise RuntimeError("bvgt_encode_values failed: %d" % r)
     return _take(b, nb.value)
+
+
+class StoredLabels:
+    """Result of store_labels: the .labels bytes, label_offsets[n+1] (bit positions) and the label class."""
+
+    def __init__(self, kind, width, stream, offsets):
+        self.kind, self.width, self.stream, self.offsets = kind, width, stream, offsets
+
+    def spec(self):
+        cls = "it.unimi.dsi.big.webgraph.labelling." + ("GammaCodedIntLabel" if self.kind == 1 else "FixedWidthIntLabel")
+        return cls + ("(FOO)" if self.kind == 1 else "(FOO,%d)" % self.width)
+
+    def write(self, basename, underlying):
+        """basename.{labels,labeloffsets,properties} as BitStreamArcLabelledImmutableGraph.store writes them (:655-700)."""
+        with open(basename + ".labels", "wb") as f:
+            f.write(self.stream.tobytes())
+        with open(basename + ".labeloffsets", "wb") as f:
+            f.write(encode_offsets(self.offsets, 2).tobytes())
+        with open(basename + ".properties", "w") as f:
+            f.write("graphclass = it.unimi.dsi.big.webgraph.labelling.BitStreamArcLabelledImmutableGraph\n"
+                    "underlyinggraph = %s\nlabelspec = %s\n" % (underlying, self.spec()))
+
+
+def store_labels(kind, width, values, arc_off):
+    """Writes one int label per arc (values[m], in successor order; arc_off[n+1] = exclusive prefix of the outdegrees)."""
+    values = np.ascontiguousarray(values, dtype=np.int32); arc_off = np.ascontiguousarray(arc_off, dtype=np.uint64)
+    n = len(arc_off) - 1
+    b = C.c_void_p(); o = C.c_void_p(); nb = C.c_uint64()
+    vbuf = values if len(values) else np.zeros(1, np.int32)
+    r = lib().bvgt_store_labels(kind, width, vbuf.ctypes.data, arc_off.ctypes.data, n, C.byref(b), C.byref(nb), C.byref(o))
+    if r:
+        raise RuntimeError("bvgt_store_labels failed: %d" % r)
+    return StoredLabels(kind, width, _take(b, nb.value), _take(o, 8 * (n + 1), np.uint64))

@@ -446,6 +446,29 @@ int bvgt_encode_values(const uint64_t* vals, int64_t count, int coding, int k, u
     return 0;
 }
 
+// BitStreamArcLabelledImmutableGraph.store (labelling/BitStreamArcLabelledImmutableGraph.java:655-680): the labels of every arc
+// in successor order (label.toBitStream: GammaCodedIntLabel.java:74-76 writeGamma, FixedWidthIntLabel.java:76-78
+// writeInt(value, width)); loffsets[n+1] = bit position of each node's run.  kind: 1 gamma, 2 fixed width.
+int bvgt_store_labels(int kind, int width, const int32_t* values, const uint64_t* arc_off, int64_t n, uint8_t** bytes, uint64_t* nbytes, uint64_t** loffsets) {
+    BitWriter w;
+    *loffsets = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+    if (!*loffsets) return BVG_E_NOMEM;
+    for (int64_t x = 0; x < n; x++) {
+        (*loffsets)[x] = w.nbits;
+        for (uint64_t a = arc_off[x]; a < arc_off[x + 1]; a++) {
+            if (kind == 1) { if (values[a] < 0) { free(*loffsets); return BVG_E_ARG; } write_gamma(w, (uint64_t)values[a]); }
+            else if (width > 0) w.put((uint64_t)(uint32_t)values[a] & (width == 32 ? 0xFFFFFFFFull : ((1ULL << width) - 1)), width);
+        }
+    }
+    (*loffsets)[n] = w.nbits;
+    w.flush();
+    *bytes = (uint8_t*)malloc(w.bytes.size() + 16);
+    if (!*bytes) { free(*loffsets); return BVG_E_NOMEM; }
+    memcpy(*bytes, w.bytes.data(), w.bytes.size()); memset(*bytes + w.bytes.size(), 0, 16);
+    *nbytes = w.bytes.size();
+    return 0;
+}
+
 void bvgt_free(void* p) { free(p); }
 
 }  // extern "C"
