@@ -152,6 +152,9 @@ typedef struct bvg_labels bvg_labels;
 int bvg_labels_parse_spec(const char* spec, int* kind, int* width);
 /* label_offsets: nodes+1 bit positions into the label stream (decode basename.labeloffsets with bvg_decode_offsets(.., BVG_GAMMA, ..)). */
 int bvg_labels_open_mem(int kind, int width, int64_t nodes, const uint8_t* stream, uint64_t nbytes, const uint64_t* label_offsets, int device, bvg_labels** out);
+/* basename.properties alone (host-only): label class and the basename of the underlying graph (property underlyinggraph,
+ * resolved against the property file, :95-97). */
+int bvg_labels_read_properties(const char* basename, int* kind, int* width, char* underlying, size_t underlying_cap);
 /* BitStreamArcLabelledImmutableGraph.load (:378-484): reads basename.{properties,labels,labeloffsets}; `underlying` receives the
  * basename of the underlying graph (property underlyinggraph, resolved against the property file), to be opened with bvg_open.
  * nodes = numNodes() of that graph. */

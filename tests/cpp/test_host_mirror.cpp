@@ -77,6 +77,16 @@ int main(int argc, char** argv) {
         uint64_t parts = 0;
         for (auto& p : g->splitNodeIterators(4)) while (p.hasNext()) { p.nextLong(); parts += (uint64_t)p.outdegree(); }
         bvg_scan_result r = g->scan();
+        if (argc > 2) {   // labelled twin: labels in successor order, every label = (source * 31 + position in the list) & 1023
+            auto lg = BitStreamArcLabelledImmutableGraph::load(argv[2]);
+            std::vector<int32_t> d, lab; std::vector<int64_t> sc;
+            lg->decodeRange(0, lg->numNodes(), d, sc, lab);
+            size_t o = 0;
+            for (int64_t x = 0; x < lg->numNodes(); x++) for (int32_t j = 0; j < d[(size_t)x]; j++, o++)
+                if (lab[o] != (int32_t)((x * 31 + j) & 1023)) { printf("FAIL label of arc %lld/%d\n", (long long)x, j); return 1; }
+            if (o != lab.size()) { printf("FAIL label count\n"); return 1; }
+            printf("LABELS %zu ok\n", o);
+        }
         printf("OK nodes=%lld arcs=%llu chk=%016llx scan_arcs=%llu scan_chk=%016llx split_arcs=%llu\n", (long long)n, (unsigned long long)arcs,
                (unsigned long long)chk, (unsigned long long)r.arcs, (unsigned long long)r.chk, (unsigned long long)parts);
         return 0;

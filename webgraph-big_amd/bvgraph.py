@@ -118,6 +118,7 @@ def lib():
         L.bvg_transpose.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_transpose_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_labels_parse_spec.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.bvg_labels_read_properties.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.bvg_labels_open_mem.argtypes = [C.c_int, C.c_int, i64, vp, u64, vp, C.c_int, pp]
         L.bvg_labels_open.argtypes = [C.c_char_p, i64, C.c_int, pp, C.c_char_p, C.c_size_t]
         L.bvg_labels_close.argtypes = [vp]; L.bvg_labels_close.restype = None
@@ -507,16 +508,9 @@ class BitStreamArcLabelledImmutableGraph:
     @classmethod
     def load(cls, basename, device=0):
         """load(basename) (:378-484): basename.properties names the underlying graph and the label class."""
-        text = open(basename + ".properties").read()
-        under = None
-        for line in text.splitlines():
-            k, _, v = line.partition("=")
-            if k.strip() == "underlyinggraph":
-                under = v.strip()
-        if under is None:
-            raise IOException(_abi.E_IO, "no underlyinggraph in %s.properties" % basename)
-        if not os.path.isabs(under):
-            under = os.path.join(os.path.dirname(basename), under)
+        buf = C.create_string_buffer(4096)
+        _check(lib().bvg_labels_read_properties(os.fsencode(basename), None, None, buf, len(buf)), "load(%s)" % basename)
+        under = os.fsdecode(buf.value)
         g = BVGraph.load(under, device)
         h = C.c_void_p()
         buf = C.create_string_buffer(4096)

@@ -132,12 +132,12 @@ int bvg_labels_open_mem(int kind, int width, int64_t nodes, const uint8_t* strea
     return 0;
 }
 
-// BitStreamArcLabelledImmutableGraph.load (:378-484): basename.properties {underlyinggraph, labelspec}, basename.labels,
-// basename.labeloffsets.  The underlying graph is opened by the caller (bvg_open) from the returned basename.
-int bvg_labels_open(const char* basename, int64_t nodes, int device, bvg_labels** out, char* underlying, size_t underlying_cap) {
-    if (!basename || !out) return BVG_E_ARG;
+// basename.properties of a BitStreamArcLabelledImmutableGraph (:95-118): the label class (labelspec) and the basename of the
+// underlying graph (underlyinggraph, resolved against the property file).  Host-only.
+int bvg_labels_read_properties(const char* basename, int* kind, int* width, char* underlying, size_t underlying_cap) {
+    if (!basename) return BVG_E_ARG;
     const std::string base(basename);
-    std::vector<uint8_t> props, lab, offs;
+    std::vector<uint8_t> props;
     int r = read_all(base + ".properties", props); if (r) return r;
     std::string spec, under;
     {
@@ -153,14 +153,27 @@ int bvg_labels_open(const char* basename, int64_t nodes, int device, bvg_labels*
         }
     }
     if (spec.empty()) return BVG_E_IO;                                        // :405 "does not contain a label specification"
-    int kind = 0, width = 0;
-    r = bvg_labels_parse_spec(spec.c_str(), &kind, &width); if (r) return r;
+    int k = 0, w = 0;
+    r = bvg_labels_parse_spec(spec.c_str(), &k, &w); if (r) return r;
+    if (kind) *kind = k;
+    if (width) *width = w;
     if (underlying && underlying_cap) {
         std::string u = under;
         if (!u.empty() && u[0] != '/') { const size_t sl = base.rfind('/'); if (sl != std::string::npos) u = base.substr(0, sl + 1) + u; }   // relative to the property file (:95-97)
         if (u.size() + 1 > underlying_cap) return BVG_E_ARG;
         memcpy(underlying, u.c_str(), u.size() + 1);
     }
+    return 0;
+}
+
+// BitStreamArcLabelledImmutableGraph.load (:378-484): basename.properties {underlyinggraph, labelspec}, basename.labels,
+// basename.labeloffsets.  The underlying graph is opened by the caller (bvg_open) from the returned basename.
+int bvg_labels_open(const char* basename, int64_t nodes, int device, bvg_labels** out, char* underlying, size_t underlying_cap) {
+    if (!basename || !out || nodes < 0) return BVG_E_ARG;
+    const std::string base(basename);
+    int kind = 0, width = 0;
+    int r = bvg_labels_read_properties(basename, &kind, &width, underlying, underlying_cap); if (r) return r;
+    std::vector<uint8_t> lab, offs;
     r = read_all(base + ".labels", lab); if (r) return r;
     r = read_all(base + ".labeloffsets", offs); if (r) return r;
     std::vector<uint64_t> lo((size_t)nodes + 1);

@@ -172,4 +172,30 @@ inline void NodeIterator::fill(int64_t x) {
 }
 inline NodeIterator NodeIterator::copy(int64_t upperBound) const { return NodeIterator(g_->copy(), curr_ + 1, upperBound, batch_); }
 
+// labelling/BitStreamArcLabelledImmutableGraph.java: an underlying BVGraph plus one int label per arc (GammaCodedIntLabel /
+// FixedWidthIntLabel), both decoded on the device.  decodeRange is one batch of the labelled node iterator (:565-582);
+// successors(x) positions at the node's label offset (:208-229).
+class BitStreamArcLabelledImmutableGraph {
+    std::shared_ptr<BVGraph> g_; bvg_labels* l_ = nullptr;
+    BitStreamArcLabelledImmutableGraph(std::shared_ptr<BVGraph> g, bvg_labels* l) : g_(std::move(g)), l_(l) {}
+public:
+    ~BitStreamArcLabelledImmutableGraph() { bvg_labels_close(l_); }
+    BitStreamArcLabelledImmutableGraph(const BitStreamArcLabelledImmutableGraph&) = delete;
+    static std::shared_ptr<BitStreamArcLabelledImmutableGraph> load(const std::string& basename, int device = 0) {     // :378-484
+        char under[4096];                                                                      // the property file names the underlying graph
+        check(bvg_labels_read_properties(basename.c_str(), nullptr, nullptr, under, sizeof under), "labels properties");
+        auto g = BVGraph::load(under, device);
+        bvg_labels* l = nullptr; check(bvg_labels_open(basename.c_str(), g->numNodes(), device, &l, nullptr, 0), "labels");
+        return std::shared_ptr<BitStreamArcLabelledImmutableGraph>(new BitStreamArcLabelledImmutableGraph(g, l));
+    }
+    std::shared_ptr<BVGraph> underlying() const { return g_; }
+    int64_t numNodes() const { return g_->numNodes(); }
+    void decodeRange(int64_t from, int64_t to, std::vector<int32_t>& deg, std::vector<int64_t>& succ, std::vector<int32_t>& lab) {
+        g_->decodeRange(from, to, deg, succ);
+        lab.resize(succ.size());
+        uint64_t n = 0;
+        check(bvg_labels_decode_range(l_, from, to, deg.data(), lab.data(), lab.size(), &n), "labels_decode_range");
+    }
+};
+
 }  // namespace webgraph
