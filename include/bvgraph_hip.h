@@ -145,8 +145,9 @@ int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t ts
  * basename.labels holds, node after node, the labels of the node's arcs in successor order (:75-84); basename.labeloffsets the
  * gamma-coded bit lengths of those runs after a leading gamma(0) (store(), :655-680).  The node iterator reads `outdegree`
  * labels per node (:565-582).  Built for the scalar label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64) and
- * FixedWidthIntLabel (FixedWidthIntLabel.java:70-73); list labels return BVG_E_UNSUPPORTED. */
-enum { BVG_LABEL_GAMMA_INT = 1, BVG_LABEL_FIXED_INT = 2 };
+ * FixedWidthIntLabel (FixedWidthIntLabel.java:70-73), and for FixedWidthIntListLabel (FixedWidthIntListLabel.java:73-78:
+ * gamma length + elements of `width` bits per arc); FixedWidthLongListLabel and user classes return BVG_E_UNSUPPORTED. */
+enum { BVG_LABEL_GAMMA_INT = 1, BVG_LABEL_FIXED_INT = 2, BVG_LABEL_FIXED_INT_LIST = 3 };
 typedef struct bvg_labels bvg_labels;
 /* Label.toSpec() text, e.g. "it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,10)" -> kind, width. */
 int bvg_labels_parse_spec(const char* spec, int* kind, int* width);
@@ -165,7 +166,11 @@ int bvg_labels_info(const bvg_labels* l, int* kind, int* width, int64_t* nodes, 
  * *n_labels = sum of the outdegrees; BVG_E_CAPACITY if cap is smaller; BVG_E_EOF if a node's run does not end at the next offset
  * (the outdegrees do not belong to this label stream). */
 int bvg_labels_decode_range(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, int32_t* labels, uint64_t cap, uint64_t* n_labels);
-/* Same, outdegrees (int32) and labels (int32) in device memory: chains with bvg_decode_range_dev without leaving HBM. */
+/* List labels (kind BVG_LABEL_FIXED_INT_LIST): list_off[arcs+1] = exclusive prefix of the list lengths of the arcs of [from,to) in
+ * successor order, values[cap] = the concatenated elements; *n_values = their number.  BVG_E_CAPACITY if cap is smaller (list_off is
+ * filled either way: size the buffer from list_off[arcs] and call again). */
+int bvg_labels_decode_range_lists(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int32_t* values, uint64_t cap, uint64_t* n_values);
+/* Same as bvg_labels_decode_range, outdegrees (int32) and labels (int32) in device memory: chains with bvg_decode_range_dev without leaving HBM. */
 int bvg_labels_decode_range_dev(bvg_labels* l, int64_t from, int64_t to, const void* d_outdeg, void* d_labels, uint64_t cap, uint64_t* n_labels);
 
 /* ---- synthetic-workload helper (bench only): K back-to-back copies of the graph ----

@@ -796,7 +796,40 @@ int bvgo_parse_label_spec(const char* spec, int* kind, int* width) {
         if (e == comma + 1 || w < 0 || w > 32) return BVGO_E_IO;
         *kind = BVGO_LABEL_FIXED_INT; *width = (int)w; return 0;
     }
+    if (cl == 22 && !strncmp(c0, "FixedWidthIntListLabel", 22)) {
+        const char* comma = memchr(lp, ',', (size_t)(rp - lp));
+        if (!comma) return BVGO_E_IO;
+        char* e = NULL; long w = strtol(comma + 1, &e, 10);
+        if (e == comma + 1 || w < 0 || w > 32) return BVGO_E_IO;
+        *kind = BVGO_LABEL_FIXED_INT_LIST; *width = (int)w; return 0;
+    }
     return BVGO_E_UNSUPPORTED;
+}
+
+/* FixedWidthIntListLabel.fromBitStream (FixedWidthIntListLabel.java:73-78): gamma(length), then `length` readInt(width).
+ * list_off[arcs+1] = exclusive prefix of the lengths; values may be NULL to size it (cap = 0). */
+int bvgo_labels_decode_lists(int width, const uint8_t* stream, uint64_t nbytes, const uint64_t* loffsets, int64_t nodes,
+                             int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int32_t* values, uint64_t cap, uint64_t* n_values) {
+    if (from < 0 || to < from || to > nodes || !loffsets || !list_off) return BVGO_E_ARG;
+    uint64_t a = 0, k = 0;
+    list_off[0] = 0;
+    for (int64_t x = from; x < to; x++) {
+        bvgo_bits b; bvgo_bits_init(&b, stream, nbytes, loffsets[x]);
+        for (int32_t j = 0; j < outdeg[x - from]; j++) {
+            uint64_t len = bvgo_read_gamma(&b);
+            if (b.err) return b.err;
+            for (uint64_t t = 0; t < len; t++) {
+                uint64_t v = bvgo_read_bits(&b, width);
+                if (b.err) return b.err;
+                if (values && k < cap) values[k] = (int32_t)(uint32_t)v;
+                k++;
+            }
+            list_off[++a] = k;
+        }
+        if (b.pos != loffsets[x + 1]) return BVGO_E_EOF;
+    }
+    if (n_values) *n_values = k;
+    return values && k > cap ? BVGO_E_ARG : 0;
 }
 
 int bvgo_labels_decode(int kind, int width, const uint8_t* stream, uint64_t nbytes, const uint64_t* loffsets, int64_t nodes,

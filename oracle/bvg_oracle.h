@@ -125,10 +125,14 @@ int bvgo_scan_mt(bvgo_graph* g, int64_t from, int64_t to, uint64_t node_base, in
 
 /* ---- arc labels stored as a bit stream: labelling/BitStreamArcLabelledImmutableGraph.java:565-582 (sequential), :208-229
  * (random access); GammaCodedIntLabel.java:60-64, FixedWidthIntLabel.java:70-73.  loffsets: nodes+1 bit positions. ---- */
-enum { BVGO_LABEL_GAMMA_INT = 1, BVGO_LABEL_FIXED_INT = 2 };
+enum { BVGO_LABEL_GAMMA_INT = 1, BVGO_LABEL_FIXED_INT = 2, BVGO_LABEL_FIXED_INT_LIST = 3 };
 int bvgo_parse_label_spec(const char* spec, int* kind, int* width);
 int bvgo_labels_decode(int kind, int width, const uint8_t* stream, uint64_t nbytes, const uint64_t* loffsets, int64_t nodes,
                        int64_t from, int64_t to, const int32_t* outdeg, int32_t* out, uint64_t cap, uint64_t* n_out);
+
+/* FixedWidthIntListLabel.java:73-78 */
+int bvgo_labels_decode_lists(int width, const uint8_t* stream, uint64_t nbytes, const uint64_t* loffsets, int64_t nodes,
+                             int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int32_t* values, uint64_t cap, uint64_t* n_values);
 
 const char* bvgo_strerror(int code);
 

@@ -77,6 +77,7 @@ def lib():
         L.bvgo_nat2int.argtypes = [u64]; L.bvgo_nat2int.restype = i64
         L.bvgo_parse_label_spec.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bvgo_labels_decode.argtypes = [C.c_int, C.c_int, vp, u64, vp, i64, i64, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvgo_labels_decode_lists.argtypes = [C.c_int, vp, u64, vp, i64, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -230,7 +231,7 @@ def mix(x, y):
     return int(lib().bvgo_mix(x, y))
 
 
-LABEL_GAMMA_INT, LABEL_FIXED_INT = 1, 2
+LABEL_GAMMA_INT, LABEL_FIXED_INT, LABEL_FIXED_INT_LIST = 1, 2, 3
 
 
 def parse_label_spec(spec):
@@ -252,3 +253,19 @@ def labels_decode(kind, width, stream, loffsets, frm, to, outdeg):
     _chk(lib().bvgo_labels_decode(kind, width, pad.ctypes.data, len(stream), lo.ctypes.data, len(lo) - 1, frm, to,
                                   deg.ctypes.data if len(deg) else None, out.ctypes.data, total, C.byref(n)))
     return out[:total]
+
+
+def labels_decode_lists(width, stream, loffsets, frm, to, outdeg):
+    """List labels (FixedWidthIntListLabel.java:73-78) of the arcs of nodes [frm,to): (list_off uint64[arcs+1], values int32)."""
+    stream = np.ascontiguousarray(np.frombuffer(bytes(stream), dtype=np.uint8))
+    pad = np.concatenate([stream, np.zeros(16, np.uint8)])
+    lo = np.ascontiguousarray(loffsets, dtype=np.uint64)
+    deg = np.ascontiguousarray(outdeg, dtype=np.int32)
+    arcs = int(deg.sum())
+    loff = np.zeros(arcs + 1, dtype=np.uint64)
+    n = C.c_uint64()
+    args = (width, pad.ctypes.data, len(stream), lo.ctypes.data, len(lo) - 1, frm, to, deg.ctypes.data if len(deg) else None, loff.ctypes.data)
+    _chk(lib().bvgo_labels_decode_lists(*args, None, 0, C.byref(n)))
+    vals = np.empty(max(n.value, 1), dtype=np.int32)
+    _chk(lib().bvgo_labels_decode_lists(*args, vals.ctypes.data, n.value, C.byref(n)))
+    return loff, vals[:n.value]

@@ -46,8 +46,9 @@ def test_label_spec_parsers_agree(W, oracle):
                        ("it.unimi.dsi.webgraph.labelling.FixedWidthIntLabel(FOO,10)", (2, 10)),
                        ("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel( weight , 32 )", (2, 32))):
         assert oracle.parse_label_spec(spec) == want and W.parse_label_spec(spec) == want
+    assert W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntListLabel(FOO,10)") == (3, 10) == oracle.parse_label_spec("x.FixedWidthIntListLabel(FOO,10)")
     with pytest.raises(W.UnsupportedOperationException):
-        W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntListLabel(FOO,10)")
+        W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthLongListLabel(FOO,40)")
     with pytest.raises(W.IOException):
         W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,33)")
 
@@ -111,3 +112,112 @@ def test_gpu_labelled_graph_from_files(W, tools, oracle, tmp_path):
     r = W.lib().bvg_labels_decode_range(lg._h, 0, n, bad.ctypes.data, out.ctypes.data, len(out), C.byref(cnt))
     assert r == W.E_EOF
     lg.close()
+
+
+# ---- the reference's own labelled test, restated: test/.../labelling/BitStreamArcLabelledGraphTest.java:210-313 (testLabels) ----
+LABEL_MASK = (1 << 31) - 1            # :45
+SIZES = (0, 1, 2, 3, 4, 7)            # :46
+WIDTHS = (-1, 0, 1, 2, 3, 8, 32, 40, 41, 63)   # :48  (-1 gamma; < 32 fixed width; >= 32 lists of elements of width - 32 bits)
+
+
+def _family(n, kind):
+    """ArrayListMutableGraph.newCompleteGraph(n, false) / newCompleteBinaryIntree(n) / newCompleteBinaryOuttree(n) (:287-289)."""
+    if kind == 0:
+        return [[y for y in range(n) if y != x] for x in range(n)]
+    if kind == 1:
+        return [[(x - 1) // 2] if x > 0 else [] for x in range(n)]
+    return [[c for c in (2 * x + 1, 2 * x + 2) if c < n] for x in range(n)]
+
+
+def _reference_labels(lists, width):
+    """createGraphWith{Gamma,FixedWidth,FixedWidthList}Labels (:127-208): label(i -> j) = (i * j + i) & LABEL_MASK (& mask)."""
+    arc_off = np.zeros(len(lists) + 1, dtype=np.uint64)
+    arc_off[1:] = np.cumsum([len(l) for l in lists]) if lists else 0
+    if width < 32:
+        mask = LABEL_MASK if width == -1 else (1 << width) - 1
+        vals = np.array([((i * j + i) & LABEL_MASK) & mask for i, l in enumerate(lists) for j in l], dtype=np.int64).astype(np.int32)
+        return arc_off, vals, None
+    w = width - 32
+    mask = (1 << w) - 1
+    lens = [(j + 1) * 2 for l in lists for j in l]                              # :165 list length (succ + 1) * 2
+    loff = np.zeros(len(lens) + 1, dtype=np.uint64)
+    loff[1:] = np.cumsum(lens) if lens else 0
+    vals = np.array([((i * k + i) & LABEL_MASK) & mask for i, l in enumerate(lists) for j in l for k in range((j + 1) * 2)], dtype=np.int64).astype(np.int32)
+    return arc_off, vals, loff
+
+
+def _store_reference_labels(tools, lists, width):
+    arc_off, vals, loff = _reference_labels(lists, width)
+    if width == -1:
+        return tools.store_labels(1, 0, vals, arc_off), arc_off, vals, None
+    if width < 32:
+        return tools.store_labels(2, width, vals, arc_off), arc_off, vals, None
+    return tools.store_label_lists(width - 32, loff, vals, arc_off), arc_off, vals, loff
+
+
+@pytest.mark.parametrize("fam", [0, 1, 2])
+def test_oracle_on_the_references_labelled_cases(tools, oracle, fam):
+    for n in SIZES:
+        lists = _family(n, fam)
+        for width in WIDTHS:
+            sl, arc_off, vals, loff = _store_reference_labels(tools, lists, width)
+            deg = np.diff(arc_off.astype(np.int64)).astype(np.int32)
+            if width < 32:
+                got = oracle.labels_decode(sl.kind, sl.width, sl.stream, sl.offsets, 0, n, deg)
+                assert np.array_equal(got, vals), (n, fam, width)
+            else:
+                lo, got = oracle.labels_decode_lists(sl.width, sl.stream, sl.offsets, 0, n, deg)
+                assert np.array_equal(lo, loff) and np.array_equal(got, vals), (n, fam, width)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fam", [0, 1, 2])
+def test_gpu_on_the_references_labelled_cases(W, tools, oracle, fam):
+    """testLabels (:210-279): sequential and random access, every node, for every size / family / width of the reference's test."""
+    for n in SIZES:
+        if n == 0:
+            continue                                                          # a graph without nodes has no device buffers to decode
+        lists = _family(n, fam)
+        st = tools.store(lists)
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+        for width in WIDTHS:
+            sl, arc_off, vals, loff = _store_reference_labels(tools, lists, width)
+            lg = W.BitStreamArcLabelledImmutableGraph.from_memory(g, sl.kind, sl.width, sl.stream, sl.offsets)
+            if width < 32:
+                deg, succ, lab = lg.decode_range(0, n)                        # sequential access
+                assert np.array_equal(lab, vals), (n, fam, width)
+                for x in range(n):                                            # random access, every node
+                    it = lg.successors(x)
+                    for j in lists[x]:
+                        assert it.next_long() == j and it.label() == int(vals[int(arc_off[x]) + lists[x].index(j)])
+                    assert it.next_long() == -1
+            else:
+                deg, succ, lo, lv = lg.decode_range_lists(0, n)
+                assert np.array_equal(lo, loff) and np.array_equal(lv, vals), (n, fam, width)
+                for x in range(n):
+                    d1, s1, lo1, lv1 = lg.decode_range_lists(x, x + 1)
+                    a, b = int(arc_off[x]), int(arc_off[x + 1])
+                    assert np.array_equal(lv1, vals[int(loff[a]):int(loff[b])]) and np.array_equal(lo1, loff[a:b + 1] - loff[a])
+            lg.close()
+        g.close()
+
+
+@pytest.mark.gpu
+def test_gpu_list_labels_on_a_synthetic_graph(W, tools, oracle):
+    n = 6000
+    st = tools.synth_store(n, seed=4, threads=2)
+    off, adj = tools.synth_adjacency(n, seed=4)
+    rng = np.random.default_rng(4)
+    m = int(off[-1])
+    lens = rng.integers(0, 6, size=m)
+    loff = np.zeros(m + 1, dtype=np.uint64); loff[1:] = np.cumsum(lens)
+    vals = rng.integers(0, 1 << 13, size=int(loff[-1]), dtype=np.int32)
+    sl = tools.store_label_lists(13, loff, vals, off)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    lg = W.BitStreamArcLabelledImmutableGraph.from_memory(g, 3, 13, sl.stream, sl.offsets)
+    deg, succ, lo, lv = lg.decode_range_lists(0, n)
+    olo, olv = oracle.labels_decode_lists(13, sl.stream, sl.offsets, 0, n, np.diff(off.astype(np.int64)).astype(np.int32))
+    assert np.array_equal(lo, olo) and np.array_equal(lv, olv) and np.array_equal(lv, vals) and np.array_equal(lo, loff)
+    with pytest.raises(W.UnsupportedOperationException):
+        lg.decode_range(0, n)                                                 # scalar entry point on a list-labelled graph
+    lg.close(); g.close()

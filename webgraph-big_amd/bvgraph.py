@@ -125,6 +125,7 @@ def lib():
         L.bvg_labels_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(u64)]
         L.bvg_labels_decode_range.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_labels_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_labels_decode_range_lists.argtypes = [vp, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_tile.argtypes = [vp, i64, pp]
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
@@ -472,7 +473,7 @@ class BVGraph:
         return r.as_dict()
 
 
-LABEL_GAMMA_INT, LABEL_FIXED_INT = 1, 2
+LABEL_GAMMA_INT, LABEL_FIXED_INT, LABEL_FIXED_INT_LIST = 1, 2, 3
 
 
 def parse_label_spec(spec):
@@ -553,6 +554,20 @@ class BitStreamArcLabelledImmutableGraph:
         d32 = np.ascontiguousarray(deg, dtype=np.int32)
         _check(lib().bvg_labels_decode_range(self._h, frm, to, d32.ctypes.data if len(d32) else None, lab.ctypes.data, len(succ), C.byref(n)), "labels(%d,%d)" % (frm, to))
         return deg, succ, lab[:len(succ)]
+
+    def decode_range_lists(self, frm, to):
+        """List labels (FixedWidthIntListLabel): (outdeg, successors, list_off[arcs+1], values)."""
+        deg, succ = self.g.decode_range(frm, to)
+        d32 = np.ascontiguousarray(deg, dtype=np.int32)
+        loff = np.zeros(len(succ) + 1, dtype=np.uint64)
+        n = C.c_uint64()
+        st = lib().bvg_labels_decode_range_lists(self._h, frm, to, d32.ctypes.data if len(d32) else None, loff.ctypes.data, None, 0, C.byref(n))
+        if st != _abi.E_CAPACITY:
+            _check(st, "label lists(%d,%d)" % (frm, to))
+        vals = np.empty(max(n.value, 1), dtype=np.int32)
+        if n.value:
+            _check(lib().bvg_labels_decode_range_lists(self._h, frm, to, d32.ctypes.data, loff.ctypes.data, vals.ctypes.data, n.value, C.byref(n)), "label lists(%d,%d)" % (frm, to))
+        return deg, succ, loff, vals[:n.value]
 
     def successors(self, x):
         """successors(x) (:208-229): a LabelledArcIterator."""

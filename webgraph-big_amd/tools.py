@@ -63,6 +63,7 @@ def lib():
         L.bvgt_encode_offsets.argtypes = [vp, i64, C.c_int, pp, C.POINTER(u64), C.POINTER(u64)]
         L.bvgt_encode_values.argtypes = [vp, i64, C.c_int, C.c_int, pp, C.POINTER(u64)]
         L.bvgt_store_labels.argtypes = [C.c_int, C.c_int, vp, vp, i64, pp, C.POINTER(u64), pp]
+        L.bvgt_store_label_lists.argtypes = [C.c_int, vp, vp, vp, i64, pp, C.POINTER(u64), pp]
         L.bvgt_free.argtypes = [vp]
         _LIB = L
     return _LIB
@@ -179,7 +180,7 @@ class StoredLabels:
         self.kind, self.width, self.stream, self.offsets = kind, width, stream, offsets
 
     def spec(self):
-        cls = "it.unimi.dsi.big.webgraph.labelling." + ("GammaCodedIntLabel" if self.kind == 1 else "FixedWidthIntLabel")
+        cls = "it.unimi.dsi.big.webgraph.labelling." + {1: "GammaCodedIntLabel", 2: "FixedWidthIntLabel", 3: "FixedWidthIntListLabel"}[self.kind]
         return cls + ("(FOO)" if self.kind == 1 else "(FOO,%d)" % self.width)
 
     def write(self, basename, underlying):
@@ -203,3 +204,16 @@ def store_labels(kind, width, values, arc_off):
     if r:
         raise RuntimeError("bvgt_store_labels failed: %d" % r)
     return StoredLabels(kind, width, _take(b, nb.value), _take(o, 8 * (n + 1), np.uint64))
+
+
+def store_label_lists(width, list_off, values, arc_off):
+    """Writes one int LIST per arc (FixedWidthIntListLabel): list_off[m+1] prefix of the list lengths, values the elements."""
+    list_off = np.ascontiguousarray(list_off, dtype=np.uint64); values = np.ascontiguousarray(values, dtype=np.int32)
+    arc_off = np.ascontiguousarray(arc_off, dtype=np.uint64)
+    n = len(arc_off) - 1
+    b = C.c_void_p(); o = C.c_void_p(); nb = C.c_uint64()
+    vbuf = values if len(values) else np.zeros(1, np.int32)
+    r = lib().bvgt_store_label_lists(width, list_off.ctypes.data, vbuf.ctypes.data, arc_off.ctypes.data, n, C.byref(b), C.byref(nb), C.byref(o))
+    if r:
+        raise RuntimeError("bvgt_store_label_lists failed: %d" % r)
+    return StoredLabels(3, width, _take(b, nb.value), _take(o, 8 * (n + 1), np.uint64))

@@ -469,6 +469,28 @@ int bvgt_store_labels(int kind, int width, const int32_t* values, const uint64_t
     return 0;
 }
 
+// List labels (FixedWidthIntListLabel.toBitStream, FixedWidthIntListLabel.java:81-85): per arc gamma(length) + the elements.
+// list_off[m+1] = exclusive prefix of the list lengths over the arcs.
+int bvgt_store_label_lists(int width, const uint64_t* list_off, const int32_t* values, const uint64_t* arc_off, int64_t n, uint8_t** bytes, uint64_t* nbytes, uint64_t** loffsets) {
+    BitWriter w;
+    *loffsets = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+    if (!*loffsets) return BVG_E_NOMEM;
+    for (int64_t x = 0; x < n; x++) {
+        (*loffsets)[x] = w.nbits;
+        for (uint64_t a = arc_off[x]; a < arc_off[x + 1]; a++) {
+            write_gamma(w, list_off[a + 1] - list_off[a]);
+            if (width > 0) for (uint64_t t = list_off[a]; t < list_off[a + 1]; t++) w.put((uint64_t)(uint32_t)values[t] & (width == 32 ? 0xFFFFFFFFull : ((1ULL << width) - 1)), width);
+        }
+    }
+    (*loffsets)[n] = w.nbits;
+    w.flush();
+    *bytes = (uint8_t*)malloc(w.bytes.size() + 16);
+    if (!*bytes) { free(*loffsets); return BVG_E_NOMEM; }
+    memcpy(*bytes, w.bytes.data(), w.bytes.size()); memset(*bytes + w.bytes.size(), 0, 16);
+    *nbytes = w.bytes.size();
+    return 0;
+}
+
 void bvgt_free(void* p) { free(p); }
 
 }  // extern "C"
