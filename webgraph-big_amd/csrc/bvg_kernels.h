@@ -8,7 +8,13 @@
 namespace bvg {
 
 // LDS geometry of the fast (one wavefront per node block) decode kernel.
-constexpr uint32_t kSkipMin = 48, kSkipEvery = 32;   // residual skip index granularity
+#ifndef BVG_SKIP_MIN
+#define BVG_SKIP_MIN 24
+#endif
+#ifndef BVG_SKIP_EVERY
+#define BVG_SKIP_EVERY 16
+#endif
+constexpr uint32_t kSkipMin = BVG_SKIP_MIN, kSkipEvery = BVG_SKIP_EVERY;   // residual skip index granularity (kSkipEvery: a power of two)
 constexpr uint32_t kAccStripes = 2048, kAccStride = 32;   // result stripes (power of two), 256 bytes apart (stripe 0 also carries 16 debug counters)
 constexpr int kRing = 128;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
 constexpr int kMaxWindow = 64;       // larger windows take the slow path only if a block needs it; beyond: unsupported
