@@ -141,6 +141,14 @@ int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);
 int bvg_transpose(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint64_t tsucc_cap, uint64_t* n_arcs);
 int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t tsucc_cap, uint64_t* n_arcs);
 
+/* Transform.symmetrizeOffline (Transform.java:546-575) = union(g, transposeOffline(g)): the SYMMETRISED graph in CSR form —
+ * soffsets[nodes+1], ssucc = for each node the increasing union of its successors and its predecessors (an arc present in both
+ * directions once; loops kept).  *n_arcs = arcs of the result, known only after the transposition: a call with too small a
+ * buffer (or ssucc NULL) returns BVG_E_CAPACITY with soffsets and *n_arcs filled and costs the full pass; 2 x numArcs() always
+ * suffices.  Requires node_base == 0. */
+int bvg_symmetrize(bvg_graph* g, uint64_t* soffsets, int64_t* ssucc, uint64_t ssucc_cap, uint64_t* n_arcs);
+int bvg_symmetrize_dev(bvg_graph* g, void* d_soffsets, void* d_ssucc, uint64_t ssucc_cap, uint64_t* n_arcs);
+
 /* ---- arc labels stored as a bit stream (labelling/BitStreamArcLabelledImmutableGraph.java) ----
  * basename.labels holds, node after node, the labels of the node's arcs in successor order (:75-84); basename.labeloffsets the
  * gamma-coded bit lengths of those runs after a leading gamma(0) (store(), :655-680).  The node iterator reads `outdegree`

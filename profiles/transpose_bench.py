@@ -24,3 +24,10 @@ for shape, synth in (("eu", T.eu_like()), ("web", T.web_like())):
     assert int(d_off[-1].item()) == m and bool((d_off[1:] >= d_off[:-1]).all())
     print("%s: %d nodes, %.2f G arcs: transpose feed %.1f ms = %.2f G arcs/s (decode + stable 64-bit radix sort of %d key bits + in-degree prefix)"
           % (shape, n, m / 1e9, dt * 1e3, m / dt / 1e9, int(np.ceil(np.log2(max(n, 2))))))
+    d_so = torch.empty(n + 1, dtype=torch.int64, device="cuda"); d_ss = torch.empty(2 * m, dtype=torch.int64, device="cuda")
+    for it in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rc = L.bvg_symmetrize_dev(g._h, d_so.data_ptr(), d_ss.data_ptr(), 2 * m, C.byref(need))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        assert rc == 0 and m <= need.value <= 2 * m, (rc, need.value, m)
+    print("%s: symmetrise (transpose feed + per-node union): %.2f G arcs out in %.1f ms = %.2f G input arcs/s" % (shape, need.value / 1e9, dt * 1e3, m / dt / 1e9))

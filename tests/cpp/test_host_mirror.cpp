@@ -71,6 +71,17 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        {   // symmetrisation: sizes, order, and symmetry of a few nodes' lists
+            std::vector<uint64_t> so; std::vector<int64_t> ss;
+            g->symmetrizeCSR(so, ss);
+            if (so.size() != (size_t)n + 1 || so[(size_t)n] != ss.size() || ss.size() < arcs || ss.size() > 2 * arcs) { printf("FAIL symmetrize size\n"); return 1; }
+            for (int64_t x : {(int64_t)0, n / 2, n - 1}) for (uint64_t t = so[(size_t)x]; t < so[(size_t)x + 1]; t++) {
+                if (t > so[(size_t)x] && ss[t - 1] >= ss[t]) { printf("FAIL symmetrize order\n"); return 1; }
+                const int64_t y = ss[t]; bool found = false;
+                for (uint64_t u = so[(size_t)y]; u < so[(size_t)y + 1] && !found; u++) found = ss[u] == x;
+                if (!found) { printf("FAIL symmetrize symmetry\n"); return 1; }
+            }
+        }
         threw = false;
         try { g->outdegree(n); } catch (const std::invalid_argument&) { threw = true; }
         if (!threw) { printf("FAIL no IllegalArgumentException\n"); return 1; }

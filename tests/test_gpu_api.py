@@ -297,3 +297,43 @@ def test_transpose_feed_matches_cpu_transpose(W, tools, oracle, small):
     with pytest.raises(W.IllegalArgumentException):
         g.transpose()
     g.set_node_base(0)
+
+
+def _cpu_symmetrize(n, deg, succ):
+    """union(g, transpose(g)) (Transform.java:573-575) with numpy: the distinct pairs of both directions, source-major."""
+    src = np.repeat(np.arange(n, dtype=np.int64), deg)
+    keys = np.unique(np.concatenate([src * n + succ, succ * n + src])) if len(succ) else np.zeros(0, np.int64)
+    s, t = keys // max(n, 1), keys % max(n, 1)
+    soff = np.concatenate([[0], np.cumsum(np.bincount(s, minlength=n))]).astype(np.uint64) if n else np.zeros(1, np.uint64)
+    return soff, t.astype(np.int64)
+
+
+def test_symmetrize_matches_cpu_union(W, tools, oracle, small):
+    """Transform.symmetrizeOffline (Transform.java:546-575): the graph united with its transpose, on the device."""
+    g, og, lists, st = small
+    n = g.num_nodes()
+    deg, succ = og.decode_range(0, n)
+    soff, ssucc = g.symmetrize()
+    csoff, cssucc = _cpu_symmetrize(n, deg, succ)
+    assert np.array_equal(soff, csoff) and np.array_equal(ssucc, cssucc)
+    # the result is its own transpose and symmetrising again changes nothing (TransformTest's checks on symmetrize)
+    s2 = tools.store((soff.astype(np.int64), ssucc), W.default_params())
+    g2 = W.BVGraph.from_memory(s2.params, s2.graph, s2.offsets)
+    toff, tsucc = g2.transpose()
+    assert np.array_equal(toff, soff) and np.array_equal(tsucc, ssucc)
+    soff2, ssucc2 = g2.symmetrize()
+    assert np.array_equal(soff2, soff) and np.array_equal(ssucc2, ssucc)
+    g2.close()
+    for ls in ([], [[]], [[0]], [[1], [0]], [[1], []], [[] for _ in range(70)], [[0, 1, 2], [2], [0]]):
+        s3 = tools.store(ls, W.default_params())
+        g3 = W.BVGraph.from_memory(s3.params, s3.graph, s3.offsets)
+        so, ss = g3.symmetrize()
+        d3 = np.array([len(l) for l in ls], dtype=np.int64); a3 = np.array([v for l in ls for v in l], dtype=np.int64)
+        cso, css = _cpu_symmetrize(len(ls), d3, a3)
+        assert np.array_equal(so, cso) and np.array_equal(ss, css), ls
+        g3.close()
+    import ctypes as C
+    need = C.c_uint64()
+    so = np.empty(n + 1, dtype=np.uint64)
+    assert W.lib().bvg_symmetrize(g._h, so.ctypes.data, None, 0, C.byref(need)) == W.E_CAPACITY and need.value == len(cssucc)
+    assert np.array_equal(so, csoff)                                           # the offsets come with the size query

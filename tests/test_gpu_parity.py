@@ -139,3 +139,14 @@ def test_cnr2000_transpose(cnr_gpu, cnr_csr):
     order = np.argsort(gsucc, kind="stable")
     assert np.array_equal(toff, np.concatenate([[0], np.cumsum(np.bincount(gsucc, minlength=n))]).astype(np.uint64))
     assert np.array_equal(tsucc, src[order])
+
+
+def test_cnr2000_symmetrize(cnr_gpu, cnr_csr):
+    """The golden graph symmetrised on the device against numpy on the golden adjacency."""
+    gdeg, gsucc = cnr_csr
+    n = len(gdeg)
+    soff, ssucc = cnr_gpu.symmetrize()
+    src = np.repeat(np.arange(n, dtype=np.int64), gdeg)
+    keys = np.unique(np.concatenate([src * n + gsucc, gsucc * n + src]))
+    assert np.array_equal(soff, np.concatenate([[0], np.cumsum(np.bincount(keys // n, minlength=n))]).astype(np.uint64))
+    assert np.array_equal(ssucc, keys % n)

@@ -117,6 +117,8 @@ def lib():
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
         L.bvg_transpose.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_transpose_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_symmetrize.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_symmetrize_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_labels_parse_spec.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bvg_labels_read_properties.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.bvg_labels_open_mem.argtypes = [C.c_int, C.c_int, i64, vp, u64, vp, C.c_int, pp]
@@ -464,6 +466,20 @@ class BVGraph:
         tsucc = np.empty(max(int(need.value), 1), dtype=np.int64)
         _check(lib().bvg_transpose(self._h, toff.ctypes.data, tsucc.ctypes.data, len(tsucc), C.byref(need)), "transpose")
         return toff, tsucc[:int(need.value)]
+
+    def symmetrize(self):
+        """The symmetrised graph in CSR form (soffsets uint64[n+1], ssucc int64): Transform.symmetrizeOffline
+        (Transform.java:546-575) = union of the graph and its transpose, computed on the device."""
+        n = self.num_nodes()
+        soff = np.empty(n + 1, dtype=np.uint64)
+        need = C.c_uint64(0)
+        ssucc = np.empty(max(2 * max(int(self._params.arcs), 0), 1), dtype=np.int64)       # 2 x arcs always suffices
+        st = lib().bvg_symmetrize(self._h, soff.ctypes.data, ssucc.ctypes.data, len(ssucc), C.byref(need))
+        if st == _abi.E_CAPACITY:                                                          # numArcs unknown in the properties
+            ssucc = np.empty(int(need.value), dtype=np.int64)
+            st = lib().bvg_symmetrize(self._h, soff.ctypes.data, ssucc.ctypes.data, len(ssucc), C.byref(need))
+        _check(st, "symmetrize")
+        return soff, ssucc[:int(need.value)]
 
     def scan(self, frm=0, to=None):
         """Full sequential successor scan consumed on chip (SpeedTest.java:127-141): dict of bvg_scan_result."""

@@ -91,6 +91,7 @@ struct bvg_graph {
     hipStream_t side[kSide] = {}; hipEvent_t side_ev[kSide] = {};
     void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
     void* tr_ws = nullptr; size_t tr_ws_bytes = 0;   // bvg_transpose workspace, kept between calls
+    size_t tr_o_cum = 0, tr_o_succ = 0;             // where the last transpose left the graph's own CSR in it (bvg_symmetrize)
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     struct Pred {
         uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
@@ -1018,6 +1019,7 @@ static int transpose_impl(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint
         }
     }
     uint64_t* const d_cum = (uint64_t*)at(o_cum); int64_t* const d_succ = (int64_t*)at(o_succ);
+    g->tr_o_cum = o_cum; g->tr_o_succ = o_succ;
     uint64_t* const d_toff = dev ? toffsets : (uint64_t*)at(o_toff); int64_t* const d_tsucc = dev ? tsucc : (int64_t*)at(o_ts);
     const auto tB = now();
     if (n > 0) {                                             // the decode: every successor list, source-major, stays in HBM
@@ -1039,6 +1041,51 @@ static int transpose_impl(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint
         if (total) HIPCHK(hipMemcpy(tsucc, d_tsucc, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
     }
     return 0;
+}
+
+// Transform.symmetrizeOffline (Transform.java:546-575) = union(g, transposeOffline(g)): the transposition feed above, then the
+// per-node sorted union of the graph's own lists (still in the transpose workspace) and the transposed ones.
+static int symmetrize_impl(bvg_graph* g, uint64_t* soffsets, int64_t* ssucc, uint64_t cap, uint64_t* n_arcs, bool dev) {
+    if (!g || !soffsets) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    const int64_t n = sh->p.nodes;
+    HIPCHK(hipSetDevice(sh->device));
+    uint64_t arcs = 0;
+    uint64_t* d_toff = nullptr; int64_t* d_ts = nullptr; int32_t* d_cnt = nullptr; uint64_t* d_soff = nullptr; uint64_t* d_tmp = nullptr; int64_t* d_out = nullptr;
+    auto done = [&](int code) { for (void* p : {(void*)d_toff, (void*)d_ts, (void*)d_cnt, (void*)d_soff, (void*)d_tmp, (void*)d_out}) if (p) (void)hipFree(p); return code; };
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    if (hipMalloc(&d_toff, (nn + 1) * 8) != hipSuccess) return done(BVG_E_NOMEM);
+    int r = transpose_impl(g, d_toff, nullptr, 0, &arcs, true);                // arc count (sum of the outdegrees)
+    if (r && r != BVG_E_CAPACITY) return done(r);
+    if (hipMalloc(&d_ts, (size_t)(arcs ? arcs : 1) * 8) != hipSuccess) return done(BVG_E_NOMEM);
+    r = transpose_impl(g, d_toff, d_ts, arcs, &arcs, true); if (r) return done(r);
+    const uint64_t* d_cum = (const uint64_t*)((char*)g->tr_ws + g->tr_o_cum); const int64_t* d_succ = (const int64_t*)((char*)g->tr_ws + g->tr_o_succ);
+    if (hipMalloc(&d_cnt, nn * 4) != hipSuccess || hipMalloc(&d_soff, (nn + 1) * 8) != hipSuccess || hipMalloc(&d_tmp, scan_tmp_elems((int64_t)nn) * 8) != hipSuccess) return done(BVG_E_NOMEM);
+    if (hipMemsetAsync(d_soff, 0, (nn + 1) * 8, g->stream) != hipSuccess) return done(BVG_E_HIP);
+    uint64_t total = 0;
+    if (n > 0) {
+        launch_union_count(d_cum, d_succ, d_toff, d_ts, n, d_cnt, g->stream);
+        launch_exclusive_scan(d_cnt, d_soff, n, d_tmp, g->stream);
+        if (hipMemcpyAsync(&total, d_soff + n, 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return done(BVG_E_HIP);
+    }
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (n_arcs) *n_arcs = total;
+    if (dev) { if (hipMemcpyAsync(soffsets, d_soff, (size_t)(n + 1) * 8, hipMemcpyDeviceToDevice, g->stream) != hipSuccess) return done(BVG_E_HIP); }
+    else if (hipMemcpy(soffsets, d_soff, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) return done(BVG_E_HIP);
+    if (total > cap || (!ssucc && total > 0)) { (void)hipStreamSynchronize(g->stream); return done(BVG_E_CAPACITY); }
+    int64_t* d_dst = ssucc;
+    if (!dev) { if (hipMalloc(&d_out, (size_t)(total ? total : 1) * 8) != hipSuccess) return done(BVG_E_NOMEM); d_dst = d_out; }
+    launch_union_write(d_cum, d_succ, d_toff, d_ts, n, d_soff, d_dst, g->stream);
+    if (!dev && total && hipMemcpyAsync(ssucc, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return done(BVG_E_HIP);
+    return done(0);
+}
+
+int bvg_symmetrize(bvg_graph* g, uint64_t* soffsets, int64_t* ssucc, uint64_t ssucc_cap, uint64_t* n_arcs) {
+    return symmetrize_impl(g, soffsets, ssucc, ssucc_cap, n_arcs, false);
+}
+int bvg_symmetrize_dev(bvg_graph* g, void* d_soffsets, void* d_ssucc, uint64_t ssucc_cap, uint64_t* n_arcs) {
+    return symmetrize_impl(g, (uint64_t*)d_soffsets, (int64_t*)d_ssucc, ssucc_cap, n_arcs, true);
 }
 
 int bvg_transpose(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint64_t tsucc_cap, uint64_t* n_arcs) {

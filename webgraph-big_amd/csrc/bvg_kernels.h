@@ -107,4 +107,8 @@ size_t transpose_temp_bytes(uint64_t arcs, int64_t n);
 hipError_t transpose_pairs(const uint64_t* cum, int64_t n, uint64_t arcs, const int64_t* succ, int64_t* src, uint64_t* keys_out, void* temp, size_t temp_bytes,
                            uint64_t* toffsets, int64_t* tsucc, unsigned* d_bad, hipStream_t s);
 
+// per-node sorted union of two CSR graphs over the same nodes (Transform.union): count pass, then write pass
+void launch_union_count(const uint64_t* acum, const int64_t* asucc, const uint64_t* bcum, const int64_t* bsucc, int64_t n, int32_t* cnt, hipStream_t s);
+void launch_union_write(const uint64_t* acum, const int64_t* asucc, const uint64_t* bcum, const int64_t* bsucc, int64_t n, const uint64_t* ocum, int64_t* out, hipStream_t s);
+
 }  // namespace bvg

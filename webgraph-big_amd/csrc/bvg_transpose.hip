@@ -6,6 +6,7 @@
 // library sort, like the reference's use of fastutil's sort), and the result is the transpose in CSR form: for every node y
 // the sources x of its incoming arcs in increasing order.  Arcs are produced in source-major order, so a stable sort on the
 // target alone leaves every list sorted.  Only the low ceil(log2 n) key bits are sorted.
+#include <cstdint>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -48,7 +49,33 @@ __global__ void offsets_from_sorted_kernel(const uint64_t* keys, uint64_t m, int
     toffsets[y] = l;
 }
 
+// Transform.union (Transform.java: the union of a graph and its transpose is symmetrizeOffline, :573-575): per node the sorted
+// union of two increasing lists, equal elements once.  One thread per node; COUNT pass sizes the lists, WRITE pass fills them.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) union_lists_kernel(const uint64_t* acum, const int64_t* asucc, const uint64_t* bcum, const int64_t* bsucc, int64_t n,
+                                                          int32_t* cnt, const uint64_t* ocum, int64_t* out) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    uint64_t i = acum[x], j = bcum[x]; const uint64_t ie = acum[x + 1], je = bcum[x + 1];
+    uint64_t k = WRITE ? ocum[x] : 0;
+    while (i < ie || j < je) {
+        const int64_t a = i < ie ? asucc[i] : INT64_MAX, b = j < je ? bsucc[j] : INT64_MAX;
+        const int64_t m = a < b ? a : b;
+        if (WRITE) out[k] = m;
+        k++;
+        i += a == m; j += b == m;
+    }
+    if (!WRITE) cnt[x] = (int32_t)k;
+}
+
 }  // namespace
+
+void launch_union_count(const uint64_t* acum, const int64_t* asucc, const uint64_t* bcum, const int64_t* bsucc, int64_t n, int32_t* cnt, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL((union_lists_kernel<false>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acum, asucc, bcum, bsucc, n, cnt, (const uint64_t*)nullptr, (int64_t*)nullptr);
+}
+void launch_union_write(const uint64_t* acum, const int64_t* asucc, const uint64_t* bcum, const int64_t* bsucc, int64_t n, const uint64_t* ocum, int64_t* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL((union_lists_kernel<true>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, acum, asucc, bcum, bsucc, n, (int32_t*)nullptr, ocum, out);
+}
 
 size_t transpose_temp_bytes(uint64_t arcs, int64_t n) {
     size_t sort_b = 0;

@@ -142,6 +142,15 @@ public:
         tsucc.resize((size_t)need);
         if (need) check(bvg_transpose(h_, toffsets.data(), tsucc.data(), need, &need), "transpose");
     }
+    // the symmetrised graph in CSR form (Transform.symmetrizeOffline, Transform.java:546-575: union with the transpose)
+    void symmetrizeCSR(std::vector<uint64_t>& soffsets, std::vector<int64_t>& ssucc) {
+        soffsets.resize((size_t)p_.nodes + 1);
+        uint64_t need = 0;
+        int st = bvg_symmetrize(h_, soffsets.data(), nullptr, 0, &need);
+        if (st != BVG_E_CAPACITY) check(st, "symmetrize");
+        ssucc.resize((size_t)need);
+        if (need) check(bvg_symmetrize(h_, soffsets.data(), ssucc.data(), need, &need), "symmetrize");
+    }
     NodeIterator nodeIterator(int64_t from = 0) { return NodeIterator(shared_from_this(), from, INT64_MAX); }   // BVGraph.java:1257
     std::vector<NodeIterator> splitNodeIterators(int howMany) {                            // ImmutableGraph.java:405-436
         std::vector<NodeIterator> v; const int64_t n = p_.nodes, m = (n + howMany - 1) / howMany;
