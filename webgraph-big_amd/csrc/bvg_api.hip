@@ -116,7 +116,7 @@ int check_params(const bvg_params& p) {
     if (!in(p.block_coding, {BVG_UNARY, BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;                // BVG:759-764
     if (!in(p.residual_coding, {BVG_GAMMA, BVG_ZETA, BVG_DELTA, BVG_GOLOMB, BVG_NIBBLE})) return BVG_E_UNSUPPORTED;  // BVG:788-795
     if (!in(p.offset_coding, {BVG_GAMMA, BVG_DELTA})) return BVG_E_UNSUPPORTED;                          // BVG:628-632
-    if (p.window_size < 0 || p.window_size > kMaxWindow) return BVG_E_UNSUPPORTED;
+    if (p.window_size < 0 || p.window_size > kMaxWindowBig) return BVG_E_UNSUPPORTED;
     if (p.min_interval_length < 0) return BVG_E_ARG;
     if (p.residual_coding == BVG_ZETA && (p.zeta_k < 1 || p.zeta_k > 32)) return BVG_E_ARG;
     return 0;
@@ -314,8 +314,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                bvg_scan_result* res, const BatchPlan* batch) {
     Shared* sh = g->sh;
     int r = 0;
+    const bool force_slow = g->tun.force_slow || sh->p.window_size > kMaxWindow;   // wide windows: the generic global-memory kernel only
     if (!batch) { r = build_plan(g, block_bits_of(g)); if (r) return r; }
-    const bool rows_default = (g->tun.reserved & 0xFF) == 0 && !g->tun.force_slow;
+    const bool rows_default = (g->tun.reserved & 0xFF) == 0 && !force_slow;
     if (!batch && rows_default && g->skip_mode == 0 && !sh->plan.skip_state && !getenv("BVG_NOSKIP") &&
         (to - from) >= sh->p.nodes / 4 && (to - from) >= 4096) { r = build_skip(g); if (r) return r; }
     const Plan& pl = sh->plan;
@@ -420,7 +421,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         return 0;
     };
     // ---- tier 0: every block, LDS sized for occupancy (the list pool holds one row of 64 lists + the window)
-    if (nblocks && !g->tun.force_slow) {
+    if (nblocks && !force_slow) {
         if (stream) {                                       // list ring: power of two
             uint64_t want = (uint64_t)(avg * 72.0), cap = 2048;
             while (cap * 2 <= want && cap < (wide ? 8192u : 16384u)) cap *= 2;
@@ -547,11 +548,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         r = fetch_failures(work); if (r) return r;
         slow_blocks = (uint32_t)work.size();
         }
-    } else if (g->tun.force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; slow_blocks = nblocks; }
+    } else if (force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; slow_blocks = nblocks; }
 
     // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with a pool sized to
     //      what each block reported it needs (size classes keep as many waves resident as possible)
-    if (!work.empty() && !g->tun.force_slow) {
+    if (!work.empty() && !force_slow) {
         std::vector<uint32_t> need(work.size());
         HIPCHK(hipMemcpy(need.data(), g->d_fail + 1 + g->fail_cap, work.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const uint32_t max_pool = wide ? 6144 : 12288;

@@ -17,8 +17,13 @@ namespace bvg {
 constexpr uint32_t kSkipMin = BVG_SKIP_MIN, kSkipEvery = BVG_SKIP_EVERY;   // residual skip index granularity (kSkipEvery: a power of two)
 constexpr uint32_t kAccStripes = 2048, kAccStride = 32;   // result stripes (power of two), 256 bytes apart (stripe 0 also carries 16 debug counters)
 constexpr int kRing = 128;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
-constexpr int kMaxWindow = 64;       // larger windows take the slow path only if a block needs it; beyond: unsupported
-constexpr int kMaxHalo = 64;         // halo nodes a block may need from before its first node (one row)
+constexpr int kMaxWindow = 64;       // window sizes up to here run in the LDS row kernels
+constexpr int kMaxHalo = 64;         // halo nodes a block may need from before its first node (one row), selected by a 64-bit mask
+// Larger windows (BVGraph allows any; LAW's "highly compressed" stores use ~70): every block takes the generic global-memory
+// kernel, whose node ring is kRingBig entries, and a block's halo is then a plain count (every halo node is decoded).
+constexpr int kRingBig = 2048;
+constexpr int kMaxWindowBig = kRingBig - 64;
+constexpr int kMaxHaloBig = 8192;
 
 struct DecodeArgs {
     const uint8_t* graph; uint64_t limit_byte;
@@ -86,6 +91,7 @@ size_t scan_tmp_elems(int64_t n);
 
 // plan: block boundaries at ~equal compressed bits, then per-boundary halo (reference-chain walk)
 void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s);
+// (window > kMaxWindow: halo = distance to the farthest node reached, up to kMaxHaloBig, mask = all ones)
 void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first, uint32_t nblk,
                       int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s);
 

@@ -56,11 +56,12 @@ template <bool GEN> struct Rd {
 template <typename T, bool MAT, bool SLOW, bool GEN>
 __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     typedef Rd<GEN> R;
-    constexpr uint32_t RM = kRing - 1;
+    constexpr int RING = SLOW ? kRingBig : kRing;                             // the global-memory tier also serves windows > kMaxWindow
+    constexpr uint32_t RM = RING - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // fast path: pool then scratch
     typedef typename std::conditional<SLOW, uint64_t, uint32_t>::type idx_t;
-    __shared__ idx_t nd_base[kRing];
-    __shared__ uint32_t nd_d[kRing];
+    __shared__ idx_t nd_base[RING];
+    __shared__ uint32_t nd_d[RING];
     __shared__ uint32_t produced[64];
     __shared__ uint32_t scr_used;
 
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     uint32_t* const stage = reinterpret_cast<uint32_t*>(dyn_lds + (SLOW ? 0 : (size_t)(a.lds_pool_elems + a.lds_scr_elems) * sizeof(T)));
     const uint32_t stage_bytes = a.lds_stage_words * 4u;
 
-    for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
+    for (unsigned i = lane; i < (unsigned)RING; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
     __syncthreads();
 
     uint64_t pool_used = 0;
@@ -89,14 +90,16 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     uint64_t blk_arcs = 0, blk_chk = 0, blk_nodes = 0;
     unsigned err = 0;
     bool failed = false;
+    const bool halo_all = W > kMaxWindow;                     // wide windows: the halo is a count, every halo node is decoded
 
     int64_t r0 = s - (int64_t)halo;
     while (r0 < e) {
         // ------------------------------------------------------------------ row set-up
+        const unsigned err_row0 = err;
         const int64_t x = r0 + lane;
         const bool in_range = x < e;
-        const uint64_t hbit = x < s ? (uint64_t)(s - 1 - x) : 0;
-        const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
+        const uint64_t hbit = x < s ? (uint64_t)(s - 1 - x) & 63u : 0;
+        const bool needed = in_range && (x >= s || halo_all || ((hmask >> hbit) & 1ull));
         uint64_t off_x = 0, rec_end = 0;
         if (in_range) { off_x = a.offsets[x]; rec_end = a.offsets[x + 1]; }
         {   // (re)stage the LDS window when this row's records are not covered by it
@@ -127,18 +130,23 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
         uint64_t total = __shfl(incl, 63, 64);
         if (total > avail && pool_used > 0) {
             // compact: keep only the lists of the last W nodes, moved to the front of the pool
-            uint64_t my_d = 0, my_base = 0; int64_t y = r0 - W + (int64_t)lane;
-            const bool livelane = (int)lane < W && y >= s - (int64_t)halo && y >= 0;
-            if (livelane) { my_d = nd_d[(uint64_t)y & RM]; my_base = nd_base[(uint64_t)y & RM]; }
-            uint64_t nincl = wave_incl_scan64(my_d);
-            uint64_t nbase = nincl - my_d;
-            for (int j = 0; j < W && j < 64; j++) {
-                uint64_t src = __shfl(my_base, j, 64), dst = __shfl(nbase, j, 64), len = __shfl(my_d, j, 64);
-                if (src != dst)
-                    for (uint64_t t = lane; t < len; t += 64) { T v = pool[src + t]; pool[dst + t] = v; }
+            uint64_t packed = 0;                                              // lists already moved to the front
+            for (int c0 = 0; c0 < W; c0 += 64) {                              // 64 of the W window nodes at a time, oldest first
+                uint64_t my_d = 0, my_base = 0; const int64_t y = r0 - W + c0 + (int64_t)lane;
+                const bool livelane = c0 + (int)lane < W && y >= s - (int64_t)halo && y >= 0;
+                if (livelane) { my_d = nd_d[(uint64_t)y & RM]; my_base = nd_base[(uint64_t)y & RM]; }
+                const uint64_t nincl = wave_incl_scan64(my_d);
+                const uint64_t nbase = packed + nincl - my_d;
+                const int cn = W - c0 < 64 ? W - c0 : 64;
+                for (int j = 0; j < cn; j++) {
+                    const uint64_t src = __shfl(my_base, j, 64), dst = __shfl(nbase, j, 64), len = __shfl(my_d, j, 64);
+                    if (src != dst)
+                        for (uint64_t t = lane; t < len; t += 64) { T v = pool[src + t]; pool[dst + t] = v; }   // (lists lie in node order: a move never lands on one not yet moved)
+                }
+                if (livelane) nd_base[(uint64_t)y & RM] = (idx_t)nbase;
+                packed += __shfl(nincl, 63, 64);
             }
-            if (livelane) nd_base[(uint64_t)y & RM] = (idx_t)nbase;
-            pool_used = __shfl(nincl, 63, 64);
+            pool_used = packed;
             avail = CAP - pool_used;
             __syncthreads();
         }
@@ -293,6 +301,9 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 if (rep && a.outdeg && !a.batch) a.outdeg[x - a.from] = (int32_t)d;
             }
         }
+        // a wide-window halo is decoded whole: its nodes that lie on no chain of this block may reference lists from before the
+        // halo, which were never decoded; whatever they report is void (each is checked as a node of its own block)
+        if (halo_all && x < s) err = err_row0;
         __syncthreads();
         r0 += k;
     }
@@ -397,6 +408,8 @@ __global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, cons
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nblk) return;
     const int64_t s = (int64_t)first[k];
+    const bool wide = window > kMaxWindow;                                    // halo as a count (up to kMaxHaloBig), no mask
+    int64_t reach = 0;
     uint64_t m = 0; bool bad = false;
     if (window > 0 && s > 0) {
         const int64_t xe = s + window < n ? s + window : n;
@@ -412,12 +425,13 @@ __global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, cons
                 y -= (int64_t)r;
                 if (y < s) {
                     int64_t dist = s - 1 - y;
-                    if (dist >= kMaxHalo) { bad = true; break; }
-                    m |= 1ull << dist;
+                    if (dist >= (wide ? kMaxHaloBig : kMaxHalo)) { bad = true; break; }
+                    if (wide) reach = dist + 1 > reach ? dist + 1 : reach; else m |= 1ull << dist;
                 }
             }
         }
     }
+    if (wide) { halo[k] = bad ? 0xFFFFFFFFu : (uint32_t)reach; mask[k] = ~0ull; return; }
     halo[k] = bad ? 0xFFFFFFFFu : (m ? 64u - (uint32_t)__builtin_clzll(m) : 0u);
     mask[k] = m;
 }

@@ -425,14 +425,14 @@ template <bool GEN>
 __global__ void __launch_bounds__(64) derive_offsets_kernel(const uint8_t* graph, uint64_t padded_bytes, uint64_t nbytes, int64_t n, int window,
                                                             int min_interval, Codings cod, uint64_t* offsets, unsigned* errp) {
     __shared__ __attribute__((aligned(16))) uint32_t ring[kDerWords];
-    __shared__ uint32_t dring[128];
+    __shared__ uint32_t dring[kRingBig];                // outdegrees of the last nodes (BVG:1030 needs outdegree(x - ref))
     const unsigned lane = threadIdx.x;
     const uint64_t total_bits = nbytes * 8;
     uint64_t whi = 0;                         // bits [whi - kDerBits, whi) are in the ring
     uint64_t pos = 0;
     unsigned err = 0;
     const uint32_t zk = (uint32_t)cod.zeta_k;
-    for (unsigned i = lane; i < 128; i += 64) dring[i] = 0;
+    for (unsigned i = lane; i < (unsigned)kRingBig; i += 64) dring[i] = 0;
     __syncthreads();
     auto ensure = [&](uint64_t upto) {        // make bits [pos, upto) available (upto - pos < ring size)
         while (whi < upto) {
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(64) derive_offsets_kernel(const uint8_t* graph
         uint64_t v;
         if (!code(cod.outdegree, 0, v) || v > 0x7FFFFFFFull) { err = ERR_OVERRUN; break; }
         const uint32_t d = (uint32_t)v;
-        dring[(uint32_t)x & 127u] = d;
+        dring[(uint32_t)x & (uint32_t)(kRingBig - 1)] = d;
         if (d > 0) {
             uint32_t ref = 0;
             if (window > 0) {
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(64) derive_offsets_kernel(const uint8_t* graph
                     tot += b; if (!(i & 1)) copied += b;
                 }
                 if (err) break;
-                if (!(bc & 1)) copied += (int64_t)dring[(uint32_t)(x - ref) & 127u] - tot;
+                if (!(bc & 1)) copied += (int64_t)dring[(uint32_t)(x - ref) & (uint32_t)(kRingBig - 1)] - tot;
                 extra = (int64_t)d - copied;
                 if (extra < 0 || copied < 0) { err = ERR_MALFORMED; break; }
             }
