@@ -165,7 +165,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         for (int i = 0; i < bvg_graph::kSide; i++) {
-            HIPCHK(hipStreamCreateWithPriority(&g->side[i], hipStreamNonBlocking, greatest));
+            HIPCHK(hipStreamCreateWithPriority(&g->side[i], hipStreamNonBlocking, getenv("BVG_PRIO") ? (atoi(getenv("BVG_PRIO")) > 0 ? greatest : atoi(getenv("BVG_PRIO")) < 0 ? least : 0) : greatest));
             HIPCHK(hipEventCreateWithFlags(&g->side_ev[i], hipEventDisableTiming));
         }
     }
@@ -507,6 +507,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
             off += pd.count[0];
             size_t offc[6]; { size_t o = 0; for (int c = 0; c < 6; c++) { offc[c] = o; o += pd.count[c]; } }
+            const bool tier0_first = getenv("BVG_ORDER") && atoi(getenv("BVG_ORDER")) == 1;
+            if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             if (pd.count[5] && gbatch) {                                       // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
@@ -523,7 +525,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 launch_rows_any(ac, pd.count[c], g->side[getenv("BVG_SIDE6") ? c : 1 + (c & 1)]);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
                 launches++;
             }
-            if (pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
+            if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
             HIPCHK(hipStreamSynchronize(g->stream));

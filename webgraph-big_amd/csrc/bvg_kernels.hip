@@ -53,10 +53,11 @@ template <bool GEN> struct Rd {
     static __device__ __forceinline__ uint64_t residual(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.residual, (unsigned)k.zeta_k, g); return c.read_zeta((unsigned)k.zeta_k, g); }
 };
 
-template <typename T, bool MAT, bool SLOW, bool GEN>
+// RING: entries of the node ring — kRing for windows up to kMaxWindow; kRingBig (24 KiB of LDS, so its own instantiation: the
+// giants of ordinary graphs run beside tier 0 and must not take its LDS) for the wide-window mode of the global-memory tier
+template <typename T, bool MAT, bool SLOW, bool GEN, int RING = kRing>
 __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
     typedef Rd<GEN> R;
-    constexpr int RING = SLOW ? kRingBig : kRing;                             // the global-memory tier also serves windows > kMaxWindow
     constexpr uint32_t RM = RING - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // fast path: pool then scratch
     typedef typename std::conditional<SLOW, uint64_t, uint32_t>::type idx_t;
@@ -522,6 +523,14 @@ void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materi
     const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
     const size_t dyn = (slow ? 0 : (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4)) + (size_t)a.lds_stage_words * 4;
+    if (a.window > kMaxWindow) {                                              // wide windows: global-memory tier only, big node ring
+        if (!slow) return;
+        if (!wide) { if (!materialise) hipLaunchKernelGGL((decode_kernel<uint32_t, false, true, true, kRingBig>), grid, block, dyn, s, a);
+                     else hipLaunchKernelGGL((decode_kernel<uint32_t, true, true, true, kRingBig>), grid, block, dyn, s, a); }
+        else { if (!materialise) hipLaunchKernelGGL((decode_kernel<uint64_t, false, true, true, kRingBig>), grid, block, dyn, s, a);
+               else hipLaunchKernelGGL((decode_kernel<uint64_t, true, true, true, kRingBig>), grid, block, dyn, s, a); }
+        return;
+    }
 #define BVG_LAUNCH2(T, M, S) do { if (gen) hipLaunchKernelGGL((decode_kernel<T, M, S, true>), grid, block, dyn, s, a); \
                                   else hipLaunchKernelGGL((decode_kernel<T, M, S, false>), grid, block, dyn, s, a); } while (0)
 #define BVG_LAUNCH(T, M, S) BVG_LAUNCH2(T, M, S)
