@@ -126,7 +126,7 @@ int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg,
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum).
  * The first scan / decode that covers >= 1/4 of the nodes also builds the residual skip index (two extra passes, once per
- * graph, shared by bvg_copy() flyweights; 8 bytes (12 for >= 2^31 nodes) per 32 residuals of lists with >= 48 residuals;
+ * graph, shared by bvg_copy() flyweights; 8 bytes (12 for >= 2^31 nodes) per 16 residuals of lists with >= 24 residuals;
  * BVG_NOSKIP=1 disables). */
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
