@@ -385,8 +385,17 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const int w = atoi(getenv("BVG_WG")); wg_nw = (w == 2 || w == 4) ? w : 0;
         }
     }
-    auto launch_rows_any = [&](const DecodeArgs& aa, uint32_t nb, hipStream_t st) {
-        if (wg_nw) launch_rows_wg_decode(aa, nb, wg_nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
+    // the big-LDS classes hold few workgroups per CU: there several wavefronts per pool pay (BVG_WGC=0|2|4 overrides)
+    int wg_class = 0;
+    {
+        const Codings& c = a.cod;
+        const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
+        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_class = getenv("BVG_WGC") ? atoi(getenv("BVG_WGC")) : 4;   // measured on the 8 GiB eu shape: 258.6 ms (0), 254.9 (2), 254.6 (4)
+        if (wg_class != 2 && wg_class != 4) wg_class = 0;
+    }
+    auto launch_rows_any = [&](const DecodeArgs& aa, uint32_t nb, hipStream_t st, bool is_class = false) {
+        const int nw = is_class && wg_class ? wg_class : wg_nw;
+        if (nw) launch_rows_wg_decode(aa, nb, nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
     };
     uint32_t launches = 0, slow_blocks = 0;
     bool predicted_run = false;                        // cascade outcomes of a predicted run are remembered in g->pred
@@ -522,7 +531,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (!pd.count[c]) continue;
                 DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_rows_any(ac, pd.count[c], g->side[getenv("BVG_SIDE6") ? c : 1 + (c & 1)]);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
+                launch_rows_any(ac, pd.count[c], g->side[getenv("BVG_SIDE6") ? c : 1 + (c & 1)], true);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
                 launches++;
             }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
@@ -572,7 +581,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             r = upload_work(); if (r) return r;
             a.lds_pool_elems = classes[c]; a.lds_scr_elems = std::max<uint32_t>(1024, classes[c] / 4); a.lds_stage_words = 1024;
             const uint32_t nb = (uint32_t)work.size();
-            r = timed("tier1 (big LDS)", nb, [&] { if (legacy) launch_decode(a, nb, wide, materialise, false, g->stream); else launch_rows_any(a, nb, g->stream); });
+            r = timed("tier1 (big LDS)", nb, [&] { if (legacy) launch_decode(a, nb, wide, materialise, false, g->stream); else launch_rows_any(a, nb, g->stream, true); });
             if (r) return r;
             launches++;
             std::vector<uint32_t> again;
