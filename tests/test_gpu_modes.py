@@ -117,3 +117,37 @@ def test_randomised_shapes(W, tools, oracle, mode):
         odeg, osucc = og.decode_range(0, n)
         assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), (trial, kw, n)
         g.close()
+
+
+def test_long_records(W, tools, oracle, monkeypatch):
+    """Records of 32-160 Kbit (thousands of far residuals) exceed the 4 KiB LDS stream window: the plan files their blocks under the
+    global-memory kernel; lists copying every other element of such a list overflow the copy-block scratch of the LDS classes and
+    cascade there too.  Whichever tier ends up decoding them, the result must agree with the oracle."""
+    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_WG"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(5)
+    n = 1 << 23                                                              # a wide id space makes the gaps (and the codes) long
+    rows = {}
+    for x in range(7, n, 600000):
+        big = np.unique(rng.integers(0, n, size=4500))                        # ~4 500 residuals x ~15 bits: ~65 Kbit
+        rows[x] = big
+        rows[x + 1] = np.unique(np.concatenate([big[::2], rng.integers(0, n, size=5)]))   # copies half of it
+    rows[1000001] = np.unique(rng.integers(0, n, size=10500))                 # ~10 500 residuals (still an LDS-sized list): > 128 Kbit
+    for x in rng.integers(0, n, size=20000):
+        rows.setdefault(int(x), np.unique(rng.integers(max(0, x - 50), min(n, x + 50), size=int(rng.integers(1, 8)))))
+    deg0 = np.zeros(n, dtype=np.int64)
+    for x, l in rows.items():
+        deg0[x] = len(l)
+    off = np.concatenate([[0], np.cumsum(deg0)]).astype(np.uint64)
+    adj = np.concatenate([rows[x] for x in sorted(rows)]).astype(np.int64)
+    st = tools.store((off, adj), W.default_params(), threads=4)
+    rec_bits = np.diff(st.offsets.astype(np.int64))
+    assert (rec_bits > 32768).sum() >= 10 and rec_bits.max() > 131072
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    og = _oracle_graph(oracle, st)
+    for _ in range(2):                                                       # second scan: learned tiers
+        r, o = g.scan(), og.scan()
+        assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"])
+    deg, succ = g.decode_range(0, n)
+    assert np.array_equal(deg, deg0) and np.array_equal(succ, adj)
+    g.close()
