@@ -132,6 +132,10 @@ int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
  * IG:405-436; cf. algo/HyperBall.java:748-768): bounds[0..k], bounds[0]=0, bounds[k]=nodes. */
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);
+/* The same with ~equal ARC counts per shard: bounds[j] = first node whose cumulative outdegree reaches j * arcs / k (the
+ * skipTo() walk over algo/EliasFanoCumulativeOutdegreeList.java:30-75 that algo/HyperBall.java:748-768 uses for its tasks);
+ * outdegrees and their prefix sum are computed on the device. */
+int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds);
 
 /* ---- transposition feed (the decode + sort of Transform.transposeOffline, Transform.java:1058-1160; processBatch :938) ----
  * Decodes every arc (x,y) of the graph on the device, sorts the pairs by target (stable radix sort, so sources stay increasing)

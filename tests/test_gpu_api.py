@@ -100,6 +100,14 @@ def test_offsets_and_outdegrees_by_products(small):
     assert b[0] == 0 and b[-1] == g.num_nodes() and all(b[i] <= b[i + 1] for i in range(4))
     bits = np.diff(st.offsets[b].astype(np.int64))
     assert bits.max() - bits.min() < int(st.offsets[-1]) // 4 // 4 + 20000     # roughly equal compressed size
+    # arc-balanced split points: exactly the skipTo() targets over the cumulative outdegrees (HyperBall.java:748-768)
+    cum = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+    for k in (1, 3, 7):
+        ba = g.split_by_arcs(k)
+        per = (int(cum[-1]) + k - 1) // k
+        want = [0] + [int(np.searchsorted(cum, j * per, side="left")) for j in range(1, k)] + [g.num_nodes()]
+        want = [min(w, g.num_nodes()) for w in want]
+        assert ba.tolist() == want, (k, ba.tolist(), want)
 
 
 def test_tile_is_a_translated_concatenation(W, small, oracle):

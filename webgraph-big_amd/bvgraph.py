@@ -115,6 +115,7 @@ def lib():
         L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
         L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
+        L.bvg_split_by_arcs.argtypes = [vp, C.c_int, vp]
         L.bvg_transpose.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_transpose_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_symmetrize.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
@@ -452,6 +453,12 @@ class BVGraph:
     def split_by_bits(self, k):
         b = np.empty(k + 1, dtype=np.int64)
         _check(lib().bvg_split_by_bits(self._h, k, b.ctypes.data), "split_by_bits")
+        return b
+
+    def split_by_arcs(self, k):
+        """Node-range split points with ~equal arc counts (HyperBall.java:748-768 over the cumulative outdegrees)."""
+        b = np.empty(k + 1, dtype=np.int64)
+        _check(lib().bvg_split_by_arcs(self._h, k, b.ctypes.data), "split_by_arcs")
         return b
 
     def transpose(self):

@@ -1107,6 +1107,31 @@ int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t ts
     return transpose_impl(g, (uint64_t*)d_toffsets, (int64_t*)d_tsucc, tsucc_cap, n_arcs, true);
 }
 
+// Arc-balanced split points (the skipTo() walk over algo/EliasFanoCumulativeOutdegreeList.java:30-75 that
+// algo/HyperBall.java:748-768 uses for its tasks): bounds[j] = first node whose cumulative outdegree reaches j * arcs / k.
+int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) {
+    if (!g || !bounds || k < 1) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    HIPCHK(hipSetDevice(sh->device));
+    const int64_t n = sh->p.nodes;
+    if (n == 0) { for (int i = 0; i <= k; i++) bounds[i] = 0; return 0; }
+    int32_t* d_deg = nullptr; uint64_t* d_cum = nullptr; uint64_t* d_tmp = nullptr; uint64_t* d_first = nullptr;
+    auto done = [&](int code) { for (void* p : {(void*)d_deg, (void*)d_cum, (void*)d_tmp, (void*)d_first}) if (p) (void)hipFree(p); return code; };
+    if (hipMalloc(&d_deg, (size_t)n * 4) != hipSuccess || hipMalloc(&d_cum, (size_t)(n + 1) * 8) != hipSuccess ||
+        hipMalloc(&d_tmp, scan_tmp_elems(n) * 8) != hipSuccess || hipMalloc(&d_first, ((size_t)k + 1) * 8) != hipSuccess) return done(BVG_E_NOMEM);
+    launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, 0, n, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
+    launch_exclusive_scan(d_deg, d_cum, n, d_tmp, g->stream);
+    uint64_t arcs = 0;
+    if (hipMemcpyAsync(&arcs, d_cum + n, 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return done(BVG_E_HIP);
+    uint64_t per = (arcs + (uint64_t)k - 1) / (uint64_t)k; if (per == 0) per = 1;
+    launch_plan_boundaries(d_cum, n, per, (uint64_t)k, d_first, g->stream);
+    std::vector<uint64_t> f((size_t)k + 1);
+    if (hipMemcpyAsync(f.data(), d_first, ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return done(BVG_E_HIP);
+    for (int i = 0; i <= k; i++) bounds[i] = (int64_t)f[(size_t)i];
+    bounds[0] = 0; bounds[k] = n;
+    return done(0);
+}
+
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) {
     if (!g || !bounds || k < 1) return BVG_E_ARG;
     Shared* sh = g->sh;
