@@ -636,7 +636,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     launch_reduce_acc(g->d_acc, kAccStripes, g->stream);
     HIPCHK(hipMemcpyAsync(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
-    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: merge steps %llu, task passes %llu (with seeks %llu), rows %llu, tasks %llu, residual steps %llu (lanes %llu)\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[19] & 0xFFFFFFFFull, acc[19] >> 32);
+    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: position steps %llu, position passes %llu, extras passes %llu, rows %llu, position tasks %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7]);
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
         fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6);
