@@ -159,11 +159,34 @@ def main():
             "host": {"generate_s": gen_s, "upload_s": upload_s, "upload_GBps": base_bytes / max(upload_s, 1e-9) / 1e9},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(st, base, threads)
+            out["cpu_baseline"] = cpu_baseline(st, base, effective_cpus(threads))     # one thread per CPU the box really grants
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def effective_cpus(threads):
+    """CPUs this process may really use: the affinity mask and the cgroup CPU quota bound the thread count."""
+    n = threads
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def cpu_baseline(st, base_gpu, threads):
@@ -172,9 +195,11 @@ def cpu_baseline(st, base_gpu, threads):
     from oracle import bvg_oracle as O
     og = O.Graph.from_memory(O.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
     n = st.params.nodes
-    reps, tm = 0, 0.0
-    while tm < 0.3 and reps < 64:                                         # ~20 core-seconds of CPU work on a 64-thread host
-        t0 = time.perf_counter(); r1 = og.scan(0, n, threads=threads); tm += time.perf_counter() - t0; reps += 1
+    reps, tm, first = 0, 0.0, None
+    while tm < 0.5 and reps < 64:                                         # sustained rate: a CPU quota lets the first burst run faster
+        t0 = time.perf_counter(); r1 = og.scan(0, n, threads=threads); dt = time.perf_counter() - t0
+        first = dt if first is None else first
+        tm += dt; reps += 1
     tm /= reps
     # also gate the GPU result on it: the first tile of shard 0 must produce the same checksum
     base_gpu.set_node_base(0)
@@ -183,7 +208,7 @@ def cpu_baseline(st, base_gpu, threads):
     # single-thread figure on a bounded sample
     sample = max(1, min(n, int(n * min(1.0, 10.0 / max(tm * threads, 1e-3)))))
     t0 = time.perf_counter(); r2 = og.scan(0, sample, threads=1); t1 = time.perf_counter() - t0
-    return {"value": r1["arcs"] / tm, "unit": "edges/s", "cores": threads, "kind": "port",
+    return {"value": r1["arcs"] / tm, "unit": "edges/s", "cores": effective_cpus(threads), "threads": threads, "value_first_scan": r1["arcs"] / first, "kind": "port",
             "sample": "base graph (1 tile: %d nodes, %d arcs), mean of %d scans with %d threads over contiguous node ranges; 1 thread on first %d nodes: %.3g edges/s"
                       % (n, r1["arcs"], reps, threads, sample, r2["arcs"] / max(t1, 1e-9)),
             "value_1thread": r2["arcs"] / max(t1, 1e-9), "gpu_matches_oracle": True}
