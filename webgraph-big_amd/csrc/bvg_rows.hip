@@ -9,10 +9,12 @@
 //   * a scratch area with the row's copy blocks and intervals.
 // Phase 1 (parse): every lane decodes its own record — outdegree gamma, reference unary, copy blocks
 // gamma, intervals gamma, residual gaps zeta_k turned into absolute values at the tail of the
-// node's own list (BVGraph.java:1003-1064).  Phase 2 (emit): a lock-step data-flow loop; per
+// node's own list (BVGraph.java:1003-1064); long residual lists are cut at their skip-index entries
+// into tasks dealt to all lanes.  Phase 2 (emit), chosen per row: a lock-step data-flow loop — per
 // iteration each lane emits one successor by the three-way merge {masked copy of the referenced
 // list, intervals, residuals} of BVGraph.java:1062-1090; a lane whose referenced list belongs to a
-// lower lane of the same row waits on that lane's `produced` counter, so reference chains pipeline.
+// lower lane of the same row waits on that lane's `produced` counter, so reference chains pipeline —
+// or (TASK variant) the level-synchronous emission by output position described at its code below.
 // The LDS footprint is kept as small as the graph allows because resident waves per CU — not HBM
 // bandwidth — bound this kernel (profiles/README.md).
 //
