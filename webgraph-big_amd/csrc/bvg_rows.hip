@@ -325,14 +325,22 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         if (a.skip_mode == 0 && sk_n != 0 && ballot(cntE != 0) && !(a.dbg & 2)) {
             // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task
             if (sk_run > sk_n) { failed = true; fail_need = 0xFFFFFFF5u; break; }      // index out of step with the stream
-            const uint32_t Tn = (parse && lane < k && nres > 0 && !bad) ? 1u + cntE : 0u;
-            const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+            // long tasks first (full segments and tails of more than kShortTask gaps), the short tails after them: a pass of 64
+            // tasks lasts as long as its longest one, so like goes with like
+            const bool hasres = parse && lane < k && nres > 0 && !bad;
+            const uint32_t lastc = nres - cntE * kSkipEvery;
+            const bool shortt = hasres && lastc <= kShortTask;
+            const uint32_t Tn = hasres ? cntE + (shortt ? 0u : 1u) : 0u;           // long tasks of this node
+            const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
+            const uint64_t smask = ballot(shortt);
+            const uint32_t ss = NL + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull)), Ttot = NL + (uint32_t)__popcll(smask);
             bool tbad = false;
             for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
                 {
                     const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
                     const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
                     for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
+                    if (shortt && ss >= p0 && ss < p0 + 64u) rtmap[ss - p0] = lane | (cntE << 8);
                 }
                 __syncthreads();
                 const bool tl = p0 + lane < Ttot;
