@@ -451,6 +451,14 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 by_tasks = (est < maxd || (a.dbg & 16u)) && !(a.dbg & 32u);
             }
             bool zbad = malf;
+            if (by_tasks && act && bc) {                                      // copy blocks -> prefix form (MaskPrefix), once per row
+                uint32_t pp = 0, kk = 0;
+                for (uint32_t i = 0; i < bc; i++) {
+                    const uint32_t b = (uint32_t)scr[sb + i];
+                    pp += b; if (!(i & 1u)) kk += b;
+                    scr[sb + i] = MaskPrefix<T>::pack(pp, kk);
+                }
+            }
             uint64_t remaining = by_tasks ? ballot(emitn) : 0ull;
             if (by_tasks && act) pool[rtb + nres] = sentinel<T>();            // guard behind the node's residual positions
             BVG_T1(0, tq0);
@@ -500,14 +508,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             uint32_t t = 0;
                             if (t_rlen) {                                     // copied elements below v: rank of its lower bound under the mask
                                 const uint32_t qq = lds_lower_bound<T>(rl, t_rlen, v);
-                                uint32_t pos = 0, qn = qq; bool kp = true, in = false;
-                                for (uint32_t bq = 0; bq < t_bc; bq++) {
-                                    const uint32_t bl = (uint32_t)scr[t_sb + bq];
-                                    if (pos + bl > qq) { if (kp) t += qq - pos; else qn = pos + bl; in = true; break; }
-                                    if (kp) t += bl;
-                                    pos += bl; kp = !kp;
-                                }
-                                if (!in) { if (kp) t += qq - pos; else qn = t_rlen; }
+                                uint32_t qn;
+                                t = MaskPrefix<T>::rank(scr + t_sb, t_bc, t_rlen, qq, qn);
                                 if (qn < t_rlen && (T)(rl[qn] - v) < (T)len) zbad = true;           // a copied element meets the extra
                             }
                             pe = eb + t;
@@ -574,20 +576,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             ie += ln;
                         }
                         const uint32_t t = p - ri - ie;                       // rank of the next copied element among the kept ones
-                        if (t_rlen) {                                         // MaskedLongIterator.java:73-100: the t-th kept position
-                            if (t_bc == 0) qcur = t;
-                            else {
-                                uint32_t pos = 0, kb = 0; bi = 0;
-                                for (;;) {
-                                    const uint32_t kl = (uint32_t)scr[t_sb + bi];
-                                    if (t < kb + kl) { qcur = pos + (t - kb); krem = kb + kl - t; bi++; break; }
-                                    kb += kl; pos += kl; bi++;
-                                    if (bi >= t_bc) { qcur = t_rlen; break; }             // an odd number of blocks: nothing is kept behind the last
-                                    pos += (uint32_t)scr[t_sb + bi]; bi++;
-                                    if (bi >= t_bc) { qcur = pos + (t - kb); break; }     // an even number: the tail is kept
-                                }
-                            }
-                        }
+                        if (t_rlen) MaskPrefix<T>::select(scr + t_sb, t_bc, t_rlen, t, qcur, krem, bi);   // MaskedLongIterator.java:73-100: the t-th kept position
                     }
                     BVG_T1(2, tq2);
                     const uint32_t tq4 = BVG_T0();
@@ -614,10 +603,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                                     }
                                 } else {
                                     qcur++;
-                                    if (--krem == 0) {                                    // MaskedLongIterator.java:81-100
-                                        if (bi >= t_bc) { qcur = t_rlen; krem = kInf; }
-                                        else { qcur += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) krem = kInf; else { krem = (uint32_t)scr[t_sb + bi]; bi++; } }
-                                    }
+                                    if (--krem == 0) MaskPrefix<T>::next_block(scr + t_sb, t_bc, t_rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
                                 }
                             }
                             p++;

@@ -45,6 +45,42 @@ template <bool GEN> __device__ __forceinline__ uint32_t read_residual(const uint
     return len;
 }
 
+// Copy blocks in PREFIX form for the position tasks: entry i = (end position of block i in the referenced list) |
+// (kept elements up to and including block i) << HS, so both directions of the copy mask (MaskedLongIterator.java:67-128) are
+// binary searches instead of walks over up to hundreds of blocks: rank of a list position among the kept ones, and the
+// position of the t-th kept element.  Blocks alternate keep / skip, block 0 keeps (and may be empty).
+template <typename T> struct MaskPrefix {
+    static constexpr uint32_t HS = sizeof(T) * 4;
+    static __device__ __forceinline__ uint32_t pos(T e) { return (uint32_t)(e & (T)(((T)1 << HS) - 1)); }
+    static __device__ __forceinline__ uint32_t kept(T e) { return (uint32_t)(e >> HS); }
+    static __device__ __forceinline__ T pack(uint32_t p, uint32_t k) { return (T)p | (T)((T)k << HS); }
+    // kept elements among list positions [0, qq); qn = the first kept position >= qq (rlen if none)
+    static __device__ __forceinline__ uint32_t rank(const T* blk, uint32_t bc, uint32_t rlen, uint32_t qq, uint32_t& qn) {
+        uint32_t lo = 0, hi = bc;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (pos(blk[mid]) > qq) hi = mid; else lo = mid + 1; }
+        const T prev = lo ? blk[lo - 1] : (T)0;
+        const bool keepb = lo < bc ? !(lo & 1u) : !(bc & 1u);                 // behind the last block: kept iff their number is even
+        if (keepb) { qn = qq; return kept(prev) + (qq - pos(prev)); }
+        qn = lo < bc ? pos(blk[lo]) : rlen;
+        return kept(prev);
+    }
+    // the t-th kept element: its list position, the kept elements left in its block (kInf behind the last block), the next block
+    static __device__ __forceinline__ void select(const T* blk, uint32_t bc, uint32_t rlen, uint32_t t, uint32_t& q, uint32_t& krem, uint32_t& bi) {
+        uint32_t lo = 0, hi = bc;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (kept(blk[mid]) > t) hi = mid; else lo = mid + 1; }
+        const T prev = lo ? blk[lo - 1] : (T)0;
+        if (lo < bc) { q = pos(prev) + (t - kept(prev)); krem = kept(blk[lo]) - t; bi = lo + 1; }
+        else if (!(bc & 1u)) { q = pos(prev) + (t - kept(prev)); krem = 0xFFFFFFFFu; bi = bc; }
+        else { q = rlen; krem = 0xFFFFFFFFu; bi = bc; }
+    }
+    // a keep block ended at block index bi - 1: skip block bi, enter keep block bi + 1
+    static __device__ __forceinline__ void next_block(const T* blk, uint32_t bc, uint32_t rlen, uint32_t& q, uint32_t& krem, uint32_t& bi) {
+        if (bi >= bc) { q = rlen; krem = 0xFFFFFFFFu; return; }
+        q = pos(blk[bi]); bi++;
+        if (bi >= bc) krem = 0xFFFFFFFFu; else { krem = pos(blk[bi]) - q; bi++; }
+    }
+};
+
 // checksum term of successor m of a node whose key is (kA, k1), kA = k0 + lo(node_base) + hi(node_base) * 0x9E3779B1: the
 // same value as mix_keyed(k0, k1, m + node_base) with the 64-bit add folded into the key (a carry adds the constant once)
 template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t kA, uint32_t k1, T m, uint32_t nbl, bool nbz) {

@@ -185,9 +185,9 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                         if (lb == 0 || rel > pend) { bad = true; bc = i; break; }
                         rel += lb;
                         const uint32_t b = (uint32_t)v + (i ? 1u : 0u);
-                        scr[sb + i] = (T)b;
                         tot += b;
                         if (!(i & 1)) copied += b;
+                        scr[sb + i] = MaskPrefix<T>::pack((uint32_t)tot, (uint32_t)copied);      // prefix form for the position tasks
                     }
                     const int64_t rlen_ = (int64_t)nd_d[(uint32_t)(x - ref) & RM];
                     if (!(bc & 1)) copied += rlen_ - tot;                     // BVG:1030
@@ -412,14 +412,8 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                             uint32_t t = 0;
                             if (t_rlen) {                                     // copied elements below: rank of the lower bound under the mask
                                 const uint32_t qq = lds_lower_bound<T>(rl, t_rlen, vv);
-                                uint32_t pos = 0, qn = qq; bool kp = true, in = false;
-                                for (uint32_t bq = 0; bq < t_bc; bq++) {
-                                    const uint32_t bl = (uint32_t)scr[t_sb + bq];
-                                    if (pos + bl > qq) { if (kp) t += qq - pos; else qn = pos + bl; in = true; break; }
-                                    if (kp) t += bl;
-                                    pos += bl; kp = !kp;
-                                }
-                                if (!in) { if (kp) t += qq - pos; else qn = t_rlen; }
+                                uint32_t qn;
+                                t = MaskPrefix<T>::rank(scr + t_sb, t_bc, t_rlen, qq, qn);
                                 if (qn < t_rlen && (T)(rl[qn] - vv) < (T)len) zbad = true;          // a copied element meets the extra
                             }
                             pe = eb + t;
@@ -483,20 +477,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                             ie += ln;
                         }
                         const uint32_t t = p - ri - ie;                       // rank of the next copied element among the kept ones
-                        if (t_rlen) {                                         // MaskedLongIterator.java:73-100: the t-th kept position
-                            if (t_bc == 0) qcur = t;
-                            else {
-                                uint32_t pos = 0, kb = 0; bi = 0;
-                                for (;;) {
-                                    const uint32_t kl = (uint32_t)scr[t_sb + bi];
-                                    if (t < kb + kl) { qcur = pos + (t - kb); krem = kb + kl - t; bi++; break; }
-                                    kb += kl; pos += kl; bi++;
-                                    if (bi >= t_bc) { qcur = t_rlen; break; }             // an odd number of blocks: nothing is kept behind the last
-                                    pos += (uint32_t)scr[t_sb + bi]; bi++;
-                                    if (bi >= t_bc) { qcur = pos + (t - kb); break; }     // an even number: the tail is kept
-                                }
-                            }
-                        }
+                        if (t_rlen) MaskPrefix<T>::select(scr + t_sb, t_bc, t_rlen, t, qcur, krem, bi);   // MaskedLongIterator.java:73-100: the t-th kept position
                     }
                     const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
                     for (;;) {
@@ -518,10 +499,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                                     }
                                 } else {
                                     qcur++;
-                                    if (--krem == 0) {                                    // MaskedLongIterator.java:81-100
-                                        if (bi >= t_bc) { qcur = t_rlen; krem = kInf; }
-                                        else { qcur += (uint32_t)scr[t_sb + bi]; bi++; if (bi >= t_bc) krem = kInf; else { krem = (uint32_t)scr[t_sb + bi]; bi++; } }
-                                    }
+                                    if (--krem == 0) MaskPrefix<T>::next_block(scr + t_sb, t_bc, t_rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
                                 }
                             }
                             p++;
