@@ -62,3 +62,11 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "bvg_oracle" not in src and "bvgo_" not in src and "from oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/bvgraph_hip.h must compile as C99 (no C++ in the signatures)."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "%s"\nint main(void) { bvg_params p; bvg_default_params(&p); return 0; }\n' % os.path.join(ROOT, "include", "bvgraph_hip.h"))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "abi.o")])
