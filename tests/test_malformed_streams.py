@@ -1,0 +1,151 @@
+"""Streams the encoder never writes: the dedup-on-equal-heads and cap-at-d branches of
+MergedLongIterator (MergedLongIterator.java:64-65,85-89), copy blocks that over-run the referenced list
+(MaskedLongIterator.java:93-100), lists that come out short and are padded with -1 (BVGraph.java:1171), and a reference to
+such a short list.  Records are hand-assembled bit by bit (tests/bvrecords.py); the expected answer is a literal Python
+restatement of the reference's iterators, which pins the C oracle on these cases (CPU test), and the HIP path must agree with
+the oracle in every emission mode (GPU test), taking its literal-iterator tier where the position tasks cannot apply.
+
+Mirrors the reference's own unit tests of the iterators (test/.../MergedLongIteratorTest.java:28-63,
+MaskedLongIteratorTest.java:29-106) at the level of whole records.
+"""
+import numpy as np
+import pytest
+
+from bvrecords import Record, assemble
+
+
+def _filler(x, k=6):
+    """A plain well-formed node: k residuals after x."""
+    return Record(d=k, residuals=[x + 3 + 5 * i for i in range(k)])
+
+
+def _cases():
+    """name -> list of Records; node 0 is always a plain 10-element list 10,20,...,100 (the referenced list)."""
+    base = Record(d=10, residuals=[10 * (i + 1) for i in range(10)])
+    C = {}
+    # residual equal to a copied element: emitted once, list one short (-1 at the end)
+    C["residual_equals_copied"] = [base, Record(d=6, ref=1, blocks=[4], residuals=[20, 35])]
+    # interval overlapping a residual (inner merge dedups): intervals [50..53], residual 52
+    C["interval_overlaps_residual"] = [base, Record(d=9, ref=1, blocks=[3], intervals=[(50, 4)], residuals=[52, 77])]
+    # interval overlapping a copied element: copied 10..40, interval [38..41] holds 40
+    C["interval_overlaps_copied"] = [base, Record(d=9, ref=1, blocks=[4], intervals=[(38, 4)], residuals=[99])]
+    # blocks over-running the referenced list, odd count: keep 3, skip 2, keep 9 (only 5 left)
+    C["blocks_overrun_odd"] = [base, Record(d=13, ref=1, blocks=[3, 2, 9], residuals=[7])]
+    # blocks over-running, even count: copied = 3 + 4 + (10 - 15) = 2 by BVG:1030, but the mask yields 3 + 4 = 7 elements:
+    # with d = 6 the outer merge stops at d with elements left (cap at d, MergedLongIterator.java:64-65)
+    C["cap_at_d"] = [base, Record(d=6, ref=1, blocks=[3, 2, 4, 6], residuals=[5, 15, 25, 1000])]
+    # everything at once + equal heads between all three streams
+    C["all_three_equal"] = [base, Record(d=12, ref=1, blocks=[5], intervals=[(28, 5)], residuals=[30, 31])]
+    # a reference to a list that came out short (its tail holds -1): node 1 is short by one, node 2 copies all of it
+    C["reference_to_short_list"] = [base, Record(d=6, ref=1, blocks=[4], residuals=[20, 35]),
+                                    Record(d=8, ref=1, blocks=[], residuals=[1, 2])]
+    # chain of depth 3 over a deduplicated list
+    C["chain_over_dedup"] = [base, Record(d=6, ref=1, blocks=[4], residuals=[20, 35]), Record(d=6, ref=1, blocks=[2, 1], residuals=[36]),
+                             Record(d=4, ref=1, blocks=[1, 1, 1], residuals=[35, 37])]
+    # first block empty, over-run inside a skip block
+    C["skip_overrun"] = [base, Record(d=4, ref=1, blocks=[0, 4, 2, 30, 1], residuals=[1])]
+    # duplicate residual next to an interval end, no reference (inner merge only)
+    C["pure_interval_residual_dup"] = [base, Record(d=7, intervals=[(200, 4)], residuals=[203, 204, 300])]
+    return C
+
+
+CASES = _cases()
+
+
+def _graph(case, pad_nodes=0, lead_nodes=0):
+    """Optionally surrounds the case with plain nodes so that it sits in the middle of a row / at a block edge."""
+    recs = list(CASES[case])
+    shift = lead_nodes
+    if shift:
+        # leading nodes first; the case's values are absolute, references relative, so only ids move
+        recs = [_filler(i) for i in range(shift)] + recs
+    recs = recs + [_filler(len(recs) + i) for i in range(pad_nodes)]
+    return recs
+
+
+def _store(W, recs):
+    g, offs, lists = assemble(recs)
+    n = len(recs)
+    p = W.default_params().clone(nodes=n, arcs=int(sum(r.d for r in recs)))
+    return p, np.frombuffer(g, dtype=np.uint8), offs, lists
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("lead,pad", [(0, 0), (5, 80), (70, 3)])
+def test_oracle_follows_the_reference_iterators(W, oracle, case, lead, pad):
+    p, g, offs, lists = _store(W, _graph(case, pad, lead))
+    og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), g.tobytes(), offs)
+    deg, succ = og.decode_range(0, p.nodes)
+    assert deg.tolist() == [len(l) for l in lists]
+    assert succ.tolist() == [v for l in lists for v in l]
+    for x in range(p.nodes):                                  # random access: recursive chains (BVG:1084)
+        assert og.successors(x).tolist() == lists[x]
+    if case != "pure_interval_residual_dup":
+        assert any(-1 in l for l in lists) or case == "cap_at_d", "the case should leave a short list"
+
+
+MODES = {
+    "default": {},
+    "tasks_every_row": dict(BVG_EMIT="1", BVG_DBG="16"),
+    "pipelined_rows_in_task_variant": dict(BVG_EMIT="1", BVG_DBG="32"),
+    "pipelined_variant": dict(BVG_EMIT="0"),
+    "workgroup_2_wavefronts": dict(BVG_EMIT="1", BVG_WG="2", BVG_DBG="16"),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", sorted(MODES))
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_hip_matches_oracle_on_streams_the_encoder_never_writes(W, oracle, monkeypatch, case, mode):
+    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_WG"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in MODES[mode].items():
+        monkeypatch.setenv(k, v)
+    for lead, pad in [(0, 0), (5, 80), (70, 3), (0, 300)]:
+        p, g, offs, lists = _store(W, _graph(case, pad, lead))
+        og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), g.tobytes(), offs)
+        hg = W.BVGraph.from_memory(p, g, offs)
+        o, r = og.scan(), hg.scan()
+        assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), (case, mode, lead, pad)
+        deg, succ = hg.decode_range(0, p.nodes)
+        assert deg.tolist() == [len(l) for l in lists]
+        assert succ.tolist() == [v for l in lists for v in l], (case, mode, lead, pad)
+        x = lead + len(CASES[case]) - 1                       # the odd node alone (random access: its chain is the halo)
+        d1, s1 = hg.decode_range(x, x + 1)
+        assert s1.tolist() == lists[x]
+        sb = hg.successors_batch(np.array([x, lead], dtype=np.int64))
+        assert sb[1].tolist() == lists[x] + lists[lead]
+        if mode == "tasks_every_row" and case not in ("pure_interval_residual_dup",):
+            # the position tasks assume disjoint streams: these rows must have been handed to the literal-iterator tier
+            assert r["slow_blocks"] > 0, "the fallback tier did not run (%s)" % case
+        hg.close()
+
+
+@pytest.mark.gpu
+def test_many_odd_nodes_among_ordinary_ones(W, oracle, tools):
+    """Odd records sprinkled over a real synthetic graph: every block that holds one falls back, the others do not."""
+    st = tools.synth_store(3000, seed=5, synth=tools.web_like(), threads=2)
+    og0 = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    deg0, succ0 = og0.decode_range(0, 3000)
+    # rebuild the graph record by record from its decoded lists (no compression: residuals only), with odd nodes mixed in
+    cum = np.concatenate([[0], np.cumsum(deg0)])
+    recs = []
+    for x in range(3000):
+        l = succ0[cum[x]:cum[x + 1]].tolist()
+        if x % 97 == 50 and len(recs) and recs[-1].d >= 4:    # copies the first 3 of the previous list and repeats one of them
+            prev = lists_prev
+            recs.append(Record(d=5, ref=1, blocks=[3], residuals=[prev[1], prev[2] + 1 if prev[2] + 1 not in prev else prev[-1] + 7]))
+            lists_prev = None
+        else:
+            recs.append(Record(d=len(l), residuals=l))
+            lists_prev = l
+    g, offs, lists = assemble(recs)
+    p = W.default_params().clone(nodes=3000, arcs=int(sum(r.d for r in recs)))
+    gb = np.frombuffer(g, dtype=np.uint8)
+    og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), g, offs)
+    hg = W.BVGraph.from_memory(p, gb, offs)
+    o, r = og.scan(), hg.scan()
+    assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"])
+    deg, succ = hg.decode_range(0, 3000)
+    assert succ.tolist() == [v for l in lists for v in l]
+    hg.close()

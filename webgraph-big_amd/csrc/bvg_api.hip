@@ -550,6 +550,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 r = fetch_failures(work); if (r) return r;
                 work.insert(work.end(), gl.begin(), gl.end());
             } else { r = fetch_failures(work); if (r) return r; }
+            slow_blocks += (uint32_t)work.size();                              // blocks the prediction missed: re-run by the cascade below
         } else {
         r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
                                               else if (legacy) launch_decode(a, nblocks, wide, materialise, false, g->stream);
