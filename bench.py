@@ -6,14 +6,23 @@
 Metric (BASELINE.json): decoded edges/s of a full sequential successor scan, plus the achieved
 fraction of the HBM-read roofline (algorithmic bytes = size of the .graph stream).
 
-Workload (config.workload): the eu-2015 configuration's synthetic stand-in — a copy-model web graph
-with default BV parameters (window 7, maxRef 3, minInterval 4, zeta_3), generated and compressed on
-the host by the repo's own encoder, then tiled on the device (bvg_tile; BV records are translation
-invariant) until the .graph stream is several GiB, i.e. far beyond the 256 MiB Infinity Cache.
-A "step" is one full scan of every node of the resident graph: successors are decoded, counted and
-checksummed on chip.  With N GPUs each rank holds one such shard of an N-times larger graph (node
-ids shifted by rank * nodes_per_shard, "weak" scaling) and the only collective is one RCCL all-reduce
-of {arcs, checksum}.  Protocol mirrors the reference's SpeedTest (3 warm-up + 10 timed scans).
+Workload (config.workload), default `--shape eu15`: the eu-2015 configuration's synthetic STAND-IN at
+eu-2015's scale — a copy-model web graph with default BV parameters (window 7, maxRef 3, minInterval 4,
+zeta_3), generated and compressed on the host by the repo's own encoder (2^21 nodes), then tiled on the
+device (bvg_tile; BV records are translation invariant) 512 times: 2^30 = 1.07 G nodes, ~91.8 G arcs
+(eu-2015: 1.07 G nodes, 91.8 G arcs), a ~29 GB .graph stream resident in HBM, two orders of magnitude
+beyond the 256 MiB Infinity Cache.  No LAW dataset can reach the GPU box (no network), hence "stand-in".
+`--shape eu` is round 1's smaller graph (8 GiB, 26 G arcs), `web` / `w0` BASELINE configs 3 / 2.
+
+A "step" is one full scan of every node of the graph: successors are decoded, counted and checksummed
+on chip.  N GPUs (one process each, launched by torch.distributed.run):
+  --scaling strong (default for N > 1; BASELINE config 5): every rank holds a replica of the ONE graph
+      and scans shard `rank` of the arc-balanced N-way node-range split (bvg_shard_bounds /
+      ImmutableGraph.splitNodeIterators); the step ends with the path's only collective, one RCCL
+      all-reduce of {arcs, chk}, and the reduced pair must equal the one-piece scan of the whole graph;
+  --scaling weak: each rank scans a whole graph of its own (node ids shifted by rank * nodes).
+Both go through webgraph-big_amd/shard.py, the helpers tests/test_multiproc_gloo.py runs over gloo.
+Protocol mirrors the reference's SpeedTest (3 warm-up + 10 timed scans).
 """
 import argparse
 import json
@@ -26,6 +35,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
+SHAPES = {
+    # name: (synth kwargs for tools.eu_like / web_like, params kwargs, default tiles of a 2^21-node base, description)
+    "eu15": ("eu", dict(mean_deg=127.5), {}, 512, "eu-2015 stand-in at eu-2015 scale: synthetic copy model, W=7 maxRef=3 minInterval=4 zeta3"),
+    "eu": ("eu", {}, {}, 0, "eu-2015-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
+    "web": ("web", {}, {}, 0, "cnr/uk-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
+    "w0": ("web", {}, dict(window_size=0, max_ref_count=0, min_interval_length=0), 0, "uk-2007-05 re-store stand-in (window=0 maxRef=0, zeta3 residuals only)"),
+}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -33,80 +50,107 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--base-nodes", type=int, default=1 << 21, help="nodes of the generated base graph")
-    ap.add_argument("--target-gib", type=float, default=8.0, help="size of the tiled .graph stream per GPU")
-    ap.add_argument("--shape", default="eu", choices=["eu", "web", "w0"], help="eu: eu-2015-like (headline); web: cnr-like; w0: window=0 residual-only (config 2)")
+    ap.add_argument("--target-gib", type=float, default=0.0, help="size of the tiled .graph stream per GPU (0 = the shape's default: 512 tiles for eu15, 8 GiB otherwise)")
+    ap.add_argument("--shape", default="eu15", choices=sorted(SHAPES))
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N > 1: strong = shards of ONE graph (default), weak = one graph per rank")
+    ap.add_argument("--balance", default="arcs", choices=["arcs", "bits", "nodes"])
     ap.add_argument("--block-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-gib", type=float, default=1.0, help="size of the stream the CPU baseline scans")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-tile checksum gate against the CPU oracle")
-    ap.add_argument("--stream", action="store_true", help="use the experimental streaming data-flow kernel as tier 0 (A/B)")
-    ap.add_argument("--grab-threshold", type=int, default=0)
-    ap.add_argument("--legacy", action="store_true", help="generic (BitCursor) row kernel as tier 0/1 (A/B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torch.distributed.run, also with one rank
+    if launched:
         args.gpus = world
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
 
     import numpy as np
     import torch
     import webgraph_big_amd as W
-    from webgraph_big_amd import tools as T
+    from webgraph_big_amd import tools as T, shard as S
 
+    torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if launched:                                                         # the process group exists whenever a launcher set the env
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
     dev = local_rank
+    cuda = torch.device("cuda", local_rank)
 
     # ---- synthetic input: generate + compress on the host, upload, tile on the device ----
     t0 = time.time()
     threads = min(os.cpu_count() or 1, 64)
-    if args.shape == "eu":
-        params, synth, wl = W.default_params(), T.eu_like(), "eu-2015-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"
-    elif args.shape == "web":
-        params, synth, wl = W.default_params(), T.web_like(), "cnr/uk-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"
-    else:
-        params, synth, wl = W.default_params(window_size=0, max_ref_count=0, min_interval_length=0), T.web_like(), "uk-2007-05 re-store stand-in (window=0 maxRef=0, zeta3 residuals only)"
+    kind, skw, pkw, tiles_default, wl = SHAPES[args.shape]
+    synth = T.eu_like(**skw) if kind == "eu" else T.web_like(**skw)
+    params = W.default_params(**pkw)
     st = T.synth_store(args.base_nodes, seed=0, params=params, synth=synth, threads=threads)
     gen_s = time.time() - t0
     base_bytes = len(st.graph)
-    copies = max(1, int(args.target_gib * (1 << 30) / max(base_bytes, 1)))
-    copies = min(copies, ((1 << 31) - 1) // args.base_nodes)          # stay on the 32-bit successor kernels
+    if args.target_gib > 0 or not tiles_default:
+        copies = max(1, int((args.target_gib or 8.0) * (1 << 30) / max(base_bytes, 1)))
+    else:
+        copies = tiles_default * (1 << 21) // args.base_nodes if args.base_nodes <= (1 << 21) else tiles_default
+    copies = max(1, min(copies, ((1 << 31) - 1) // args.base_nodes))    # stay on the 32-bit successor kernels
+    free0 = torch.cuda.mem_get_info(dev)[0]
     t0 = time.time()
     base = W.BVGraph.from_memory(st.params, st.graph, st.offsets, device=dev)
     torch.cuda.synchronize()
     upload_s = time.time() - t0
+    t0 = time.time()
     g = base.tile(copies) if copies > 1 else base
-    if args.block_bits or args.stream or args.grab_threshold or args.legacy:
-        g.set_tuning(block_bits=args.block_bits, stream=args.stream, grab_threshold=args.grab_threshold, legacy=args.legacy)
-    n_local = g.num_nodes()
-    g.set_node_base(rank * n_local)                                     # shard `rank` of the N-times larger graph
-    arcs_local = st.stats["arcs"] * copies
+    torch.cuda.synchronize()
+    tile_s = time.time() - t0
+    if args.block_bits:
+        g.set_tuning(block_bits=args.block_bits)
+    n_graph = g.num_nodes()
+    arcs_graph = st.stats["arcs"] * copies
+    bal = {"arcs": W.BALANCE_ARCS, "bits": W.BALANCE_BITS, "nodes": W.BALANCE_NODES}[args.balance]
+    if scaling == "strong":
+        bounds = g.shard_bounds(world, bal)                              # shard `rank` of the ONE graph
+        my_rank = rank
+    else:
+        g.set_node_base(rank * n_graph)                                  # a graph of its own per rank, ids shifted
+        bounds = np.array([0, n_graph], dtype=np.int64)
+        my_rank = 0
+    lo, hi = int(bounds[my_rank]), int(bounds[my_rank + 1])
 
     def step():
-        return g.scan()
+        # the hot path of this rank + the path's only collective (16 bytes over RCCL when a process group exists)
+        return S.sharded_scan(lambda a, b: g.scan(a, b), bounds, my_rank, device=cuda if dist is not None else None, reduce=dist is not None)
 
-    r = step()                                                          # correctness gate (untimed)
+    t0 = time.time()
+    r, tot_arcs, tot_chk = step()                                        # first scan: builds the block plan and the residual skip index
+    torch.cuda.synchronize()
+    first_scan_s = time.time() - t0
     for _ in range(args.warmup):
-        r = step()
-    # correctness gate: arcs must equal the encoder's count, and the first, middle and last tile of this shard, scanned
-    # through the very handle that is timed, must give the checksum the CPU oracle computes for that node range
-    assert r["arcs"] == arcs_local and r["nodes"] == n_local, (r, arcs_local, n_local)
+        r, tot_arcs, tot_chk = step()
+    resident = free0 - torch.cuda.mem_get_info(dev)[0]
+    # ---- correctness gate (untimed) ----
+    want_arcs = arcs_graph if scaling == "strong" else arcs_graph * world
+    assert tot_arcs == want_arcs, (tot_arcs, want_arcs)
+    if scaling == "weak":
+        assert r["arcs"] == arcs_graph and r["nodes"] == n_graph, (r, arcs_graph, n_graph)
     if not args.no_verify:
+        # the first, middle and last tile of this rank's node range, scanned through the very handle that is timed, must give the
+        # checksum the CPU oracle computes for those nodes
         from oracle import bvg_oracle as O
         og = O.Graph.from_memory(O.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
         n0 = st.params.nodes
-        for j in sorted({0, copies // 2, copies - 1}):
-            ro = og.scan(0, n0, node_base=rank * n_local + j * n0, threads=threads)
+        nb = rank * n_graph if scaling == "weak" else 0
+        j_lo, j_hi = (lo + n0 - 1) // n0, hi // n0                       # whole tiles inside [lo, hi)
+        for j in sorted({j_lo, (j_lo + j_hi) // 2, j_hi - 1}) if j_hi > j_lo else []:
+            ro = og.scan(0, n0, node_base=nb + j * n0, threads=threads)
             rg = g.scan(j * n0, (j + 1) * n0)
             assert (rg["arcs"], rg["chk"]) == (ro["arcs"], ro["chk"]), "GPU scan of tile %d disagrees with the CPU oracle" % j
         del og
+    if scaling == "strong" and world > 1 and rank == 0:
+        whole = g.scan()                                                 # the one-piece scan of the replica: what the shards must add up to
+        assert (whole["arcs"], whole["chk"]) == (tot_arcs, tot_chk), "reduced shards disagree with the one-piece scan"
 
     if dist is not None:
         dist.barrier()
@@ -114,56 +158,65 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
-        r = step()
+        r, tot_arcs, tot_chk = step()
         kernel_ms.append(r["kernel_ms"])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-
-    tot_arcs, tot_chk = r["arcs"], r["chk"]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # the only collective of the path: {arcs, checksum} summed mod 2^64 (int64 wrap-around == uint64 sum)
-        red = torch.tensor([np.int64(np.uint64(tot_arcs).astype(np.int64)), np.uint64(tot_chk).astype(np.int64)], dtype=torch.int64, device="cuda")
-        dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        tot_arcs = int(np.int64(red[0].item()).astype(np.uint64)); tot_chk = int(np.int64(red[1].item()).astype(np.uint64))
+        elapsed = S.allreduce_max(elapsed, device=cuda)
+        k_ms = S.allreduce_max(float(np.mean(kernel_ms)), device=cuda)
     else:
-        tot_arcs, tot_chk = int(tot_arcs), int(tot_chk)
+        k_ms = float(np.mean(kernel_ms))
 
     if rank == 0:
         edges_per_s = tot_arcs * args.steps / elapsed
-        k_ms = float(np.mean(kernel_ms))
-        gbs = r["graph_bytes"] / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.shape, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        gbytes = r["graph_bytes"]                                        # this rank's shard (strong) or graph (weak)
+        total_gbytes = (int(st.offsets[-1]) * copies + 7) // 8 * (1 if scaling == "strong" else world)
+        gbs = gbytes / (k_ms * 1e-3) / 1e9                               # per-GPU rate of the dominant kernel family
+        steady_s = elapsed / args.steps
         out = {
             "metric": "decoded edges/s, full sequential successor scan", "value": edges_per_s, "unit": "edges/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32" if n_local < (1 << 31) else "u64",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": steady_s * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32" if n_graph < (1 << 31) else "u64",
             "data": "synthetic",
-            "config": {"workload": wl, "nodes_per_gpu": n_local, "arcs_per_gpu": arcs_local, "graph_bytes_per_gpu": r["graph_bytes"],
-                       "bits_per_link": 8.0 * r["graph_bytes"] / arcs_local, "tiles": copies, "base_nodes": args.base_nodes,
-                       "sharding": "node ranges, %d shard(s); RCCL all-reduce of {arcs,chk} only" % args.gpus},
+            "config": {"workload": wl + (" [stand-in: no LAW dataset on the box]" if args.shape == "eu15" else ""), "shape": args.shape,
+                       "nodes": n_graph * (world if scaling == "weak" else 1), "arcs": tot_arcs, "graph_bytes": total_gbytes,
+                       "nodes_per_gpu": hi - lo, "arcs_per_gpu": int(r["arcs"]), "graph_bytes_per_gpu": gbytes,
+                       "bits_per_link": 8.0 * gbytes / max(int(r["arcs"]), 1), "tiles": copies, "base_nodes": args.base_nodes,
+                       "sharding": ("%d arc-balanced node-range shard(s) of one graph, a replica per GPU" % world if scaling == "strong" else "%d graph(s), one per GPU, ids shifted" % world)
+                                   + "; RCCL all-reduce of {arcs,chk} only"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "bvg::rows_kernel<u32,scan,tasks> (tier 0) + rows_wg_kernel<u32,4> (big-LDS classes) + decode_kernel<slow> (giants) + reduce_acc_kernel, launched concurrently: hipEvent time of one scan", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": r["graph_bytes"], "index_bytes_per_launch": r["index_bytes"]},
+                         "traffic": None, "traffic_source": None,
+                         "kernel": "bvg::rows_kernel<u32,scan,tasks> (tier 0) with rows_wg_kernel<u32,4> (big-LDS classes), decode_kernel<slow> (giants) and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": gbytes, "index_bytes_per_launch": r["index_bytes"]},
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
-            "host": {"generate_s": gen_s, "upload_s": upload_s, "upload_GBps": base_bytes / max(upload_s, 1e-9) / 1e9},
+            "index_build_s": max(first_scan_s - steady_s, 0.0), "hbm_resident_bytes": int(resident),
+            "host": {"generate_s": gen_s, "upload_s": upload_s, "tile_s": tile_s, "first_scan_s": first_scan_s},
         }
+        t = measured_traffic(args.shape, copies, args.base_nodes, world, scaling)
+        if t:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(st, base, effective_cpus(threads))     # one thread per CPU the box really grants
+            out["cpu_baseline"] = cpu_baseline(st, base, effective_cpus(threads), args.cpu_gib)   # one thread per CPU the box really grants
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(shape, tiles, base_nodes, world, scaling):
+    """HBM bytes per launch from a PMC pass of THIS workload, if one is on file (profiles/traffic.json, written by
+    profiles/r02/collect_pmc.py with the configuration it was measured on); never a figure from another configuration."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return None
+    for e in rec.get("runs", []):
+        if (e.get("shape"), e.get("tiles"), e.get("base_nodes"), e.get("n_gpus", 1), e.get("scaling", "weak")) == (shape, tiles, base_nodes, world, scaling if world > 1 else e.get("scaling", "weak")):
+            return e["hbm_bytes_per_launch"], e.get("source")
+    return None
 
 
 def effective_cpus(threads):
@@ -189,28 +242,35 @@ def effective_cpus(threads):
     return n
 
 
-def cpu_baseline(st, base_gpu, threads):
-    """The CPU oracle (a C port of the reference's decode path) timed on this box's host cores over the
-    base graph (one tile of the workload), node ranges split as ImmutableGraph.splitNodeIterators does."""
+def cpu_baseline(st, base_gpu, threads, gib):
+    """The CPU oracle (a C PORT of the reference's decode path: no JVM exists here, so not the reference itself) timed on this
+    box's host cores over a `gib`-GiB prefix of the workload (tiles of the base graph, concatenated on the host exactly as
+    bvg_tile does on the device), node ranges split as ImmutableGraph.splitNodeIterators does."""
+    import numpy as np
     from oracle import bvg_oracle as O
-    og = O.Graph.from_memory(O.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
-    n = st.params.nodes
-    reps, tm, first = 0, 0.0, None
-    while tm < 0.5 and reps < 64:                                         # sustained rate: a CPU quota lets the first burst run faster
+    from webgraph_big_amd import tools as T
+    k = max(1, int(round(gib * (1 << 30) / max(len(st.graph), 1))))
+    ts = T.tile_host(st, k)
+    og = O.Graph.from_memory(O.Params(**ts.params.as_dict()), ts.graph.tobytes(), ts.offsets)
+    n = ts.params.nodes
+    reps, tm, first, r1 = 0, 0.0, None, None
+    while (tm < 10.0 and reps < 64) or reps < 2:                          # sustained rate: a CPU quota lets the first burst run faster
         t0 = time.perf_counter(); r1 = og.scan(0, n, threads=threads); dt = time.perf_counter() - t0
         first = dt if first is None else first
         tm += dt; reps += 1
     tm /= reps
-    # also gate the GPU result on it: the first tile of shard 0 must produce the same checksum
+    # also gate the GPU result on it: the first tile of the workload must produce the same checksum
+    n0 = st.params.nodes
+    r0 = og.scan(0, n0, threads=threads)
     base_gpu.set_node_base(0)
     rg = base_gpu.scan()
-    assert (rg["arcs"], rg["chk"]) == (r1["arcs"], r1["chk"]), "GPU scan disagrees with the CPU oracle"
-    # single-thread figure on a bounded sample
-    sample = max(1, min(n, int(n * min(1.0, 10.0 / max(tm * threads, 1e-3)))))
+    assert (rg["arcs"], rg["chk"]) == (r0["arcs"], r0["chk"]), "GPU scan disagrees with the CPU oracle"
+    # single-thread figure on a bounded sample (~5 s)
+    sample = max(1, min(n, int(n * min(1.0, 5.0 / max(tm * threads, 1e-3)))))
     t0 = time.perf_counter(); r2 = og.scan(0, sample, threads=1); t1 = time.perf_counter() - t0
-    return {"value": r1["arcs"] / tm, "unit": "edges/s", "cores": effective_cpus(threads), "threads": threads, "value_first_scan": r1["arcs"] / first, "kind": "port",
-            "sample": "base graph (1 tile: %d nodes, %d arcs), mean of %d scans with %d threads over contiguous node ranges; 1 thread on first %d nodes: %.3g edges/s"
-                      % (n, r1["arcs"], reps, threads, sample, r2["arcs"] / max(t1, 1e-9)),
+    return {"value": r1["arcs"] / tm, "unit": "edges/s", "cores": threads, "threads": threads, "value_first_scan": r1["arcs"] / first, "kind": "port",
+            "sample": "first %d tiles of the workload (%d nodes, %d arcs, %.2f GiB of .graph), mean of %d scans with %d threads over contiguous node ranges; 1 thread on the first %d nodes: %.3g edges/s"
+                      % (k, n, r1["arcs"], len(ts.graph) / (1 << 30), reps, threads, sample, r2["arcs"] / max(t1, 1e-9)),
             "value_1thread": r2["arcs"] / max(t1, 1e-9), "gpu_matches_oracle": True}
 
 

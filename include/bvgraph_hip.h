@@ -137,6 +137,23 @@ int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);
  * outdegrees and their prefix sum are computed on the device. */
 int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds);
 
+/* ---- node-range shards over several GPUs (ImmutableGraph.splitNodeIterators, IG:405-436; arc-balanced tasks as in
+ * algo/HyperBall.java:748-768).  Shards are independent: each decodes its own node range (and re-derives its halo locally), the
+ * only thing ever combined is {nodes, arcs, chk}, by a plain sum. ---- */
+enum { BVG_BALANCE_NODES = 0,   /* ceil(n/k) nodes per shard: the reference's rule, IG:415-433 */
+       BVG_BALANCE_BITS = 1,    /* ~equal compressed bits (bvg_split_by_bits) */
+       BVG_BALANCE_ARCS = 2 };  /* ~equal arc counts (bvg_split_by_arcs) */
+/* bounds[0..k] of the k-way split; cached in the graph, so flyweights and later calls agree. */
+int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds);
+/* The scan of shard r of k: nodes [bounds[r], bounds[r+1]) (returned in *from / *to when not NULL).  One rank of a
+ * one-process-per-GPU job calls this on its replica and all-reduces {arcs, chk} (RCCL: 16 bytes); the sum over r = 0..k-1
+ * equals bvg_scan(g, 0, nodes). */
+int bvg_scan_shard(bvg_graph* g, int k, int r, int balance, bvg_scan_result* out, int64_t* from, int64_t* to);
+/* One process, ngpu devices (a JVM host): per_gpu[i] = a handle of the SAME graph on device i (or bvg_copy() flyweights on
+ * one device); shard i runs on per_gpu[i], all shards concurrently, results summed on the host (total; per_shard[ngpu]
+ * optional).  total->kernel_ms = the slowest shard. */
+int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_result* total, bvg_scan_result* per_shard);
+
 /* ---- transposition feed (the decode + sort of Transform.transposeOffline, Transform.java:1058-1160; processBatch :938) ----
  * Decodes every arc (x,y) of the graph on the device, sorts the pairs by target (stable radix sort, so sources stay increasing)
  * and returns the TRANSPOSE in CSR form: toffsets[nodes+1] = exclusive prefix of the in-degrees, tsucc[arcs] = for each node y

@@ -116,6 +116,9 @@ def lib():
         L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
         L.bvg_split_by_arcs.argtypes = [vp, C.c_int, vp]
+        L.bvg_shard_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.bvg_scan_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(ScanResult), C.POINTER(i64), C.POINTER(i64)]
+        L.bvg_scan_multi.argtypes = [vp, C.c_int, C.c_int, C.POINTER(ScanResult), vp]
         L.bvg_transpose.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_transpose_dev.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_symmetrize.argtypes = [vp, vp, vp, u64, C.POINTER(u64)]
@@ -461,6 +464,19 @@ class BVGraph:
         _check(lib().bvg_split_by_arcs(self._h, k, b.ctypes.data), "split_by_arcs")
         return b
 
+    def shard_bounds(self, k, balance=None):
+        """bounds[0..k] of the k-way node-range split (bvg_shard_bounds): BALANCE_NODES is ImmutableGraph.java:415-433."""
+        b = np.empty(k + 1, dtype=np.int64)
+        _check(lib().bvg_shard_bounds(self._h, k, BALANCE_ARCS if balance is None else balance, b.ctypes.data), "shard_bounds")
+        return b
+
+    def scan_shard(self, k, r, balance=None):
+        """The scan of shard r of k (bvg_scan_shard): dict of bvg_scan_result plus 'from' / 'to'."""
+        res = ScanResult(); lo = C.c_int64(); hi = C.c_int64()
+        _check(lib().bvg_scan_shard(self._h, k, r, BALANCE_ARCS if balance is None else balance, C.byref(res), C.byref(lo), C.byref(hi)), "scan_shard(%d,%d)" % (k, r))
+        d = res.as_dict(); d["from"] = lo.value; d["to"] = hi.value
+        return d
+
     def transpose(self):
         """The transpose in CSR form (toffsets uint64[n+1], tsucc int64[arcs]): the decode + sort of Transform.transposeOffline
         (Transform.java:1058-1160) done on the device; sources of every node's incoming arcs in increasing order."""
@@ -494,6 +510,18 @@ class BVGraph:
         r = ScanResult()
         _check(lib().bvg_scan(self._h, frm, to, C.byref(r)), "scan(%d,%d)" % (frm, to))
         return r.as_dict()
+
+
+BALANCE_NODES, BALANCE_BITS, BALANCE_ARCS = 0, 1, 2
+
+
+def scan_multi(graphs, balance=BALANCE_ARCS):
+    """bvg_scan_multi: graphs[i] scans shard i of len(graphs) on its own device, all at once; returns (total, [per shard])."""
+    k = len(graphs)
+    hs = (C.c_void_p * k)(*[g._h for g in graphs])
+    tot = ScanResult(); per = (ScanResult * k)()
+    _check(lib().bvg_scan_multi(hs, k, balance, C.byref(tot), per), "scan_multi")
+    return tot.as_dict(), [p.as_dict() for p in per]
 
 
 LABEL_GAMMA_INT, LABEL_FIXED_INT, LABEL_FIXED_INT_LIST = 1, 2, 3

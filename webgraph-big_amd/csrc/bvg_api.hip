@@ -14,8 +14,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvg_kernels.h"
@@ -44,7 +47,7 @@ struct Plan {
     std::vector<uint32_t> h_maxd;             // largest (list + the W lists before it) a block decodes: predicts its tier
     uint64_t version = 0;
     // residual skip index (built by two passes of the row kernel the first time a large range is decoded)
-    int skip_state = 0;                       // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index)
+    std::atomic<int> skip_state{0};           // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index); published with release order
     uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint32_t* d_skip_bit = nullptr; void* d_skip_val = nullptr;
     bool skip_wide = false;                   // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
     std::vector<uint64_t> h_skip_first;
@@ -52,7 +55,7 @@ struct Plan {
         if (d_skip_first) (void)hipFree(d_skip_first);
         if (d_skip_bit) (void)hipFree(d_skip_bit);
         if (d_skip_val) (void)hipFree(d_skip_val);
-        d_skip_first = nullptr; d_skip_bit = nullptr; d_skip_val = nullptr; skip_total = 0; skip_state = 0; h_skip_first.clear();
+        d_skip_first = nullptr; d_skip_bit = nullptr; d_skip_val = nullptr; skip_total = 0; skip_state.store(0); h_skip_first.clear();
     }
     void release() {
         release_skip();
@@ -61,6 +64,11 @@ struct Plan {
         if (d_mask) (void)hipFree(d_mask);
         d_first = nullptr; d_halo = nullptr; d_mask = nullptr; nblk = 0; h_first.clear(); h_maxd.clear();
     }
+    int device = 0;
+    Plan() = default;
+    Plan(const Plan&) = delete;
+    Plan& operator=(const Plan&) = delete;
+    ~Plan() { (void)hipSetDevice(device); release(); }
 };
 
 struct Shared {
@@ -70,7 +78,14 @@ struct Shared {
     uint64_t* d_offsets = nullptr; bool own_offsets = false;
     uint64_t total_bits = 0;
     bool wide = false;
-    Plan plan; std::mutex mu; std::mutex skip_mu;
+    // Block plans are immutable once built and shared by reference count: a handle holds the one it decodes with for the whole
+    // call, so a bvg_copy() flyweight asking for another block size (bvg_set_tuning) on another thread can never free arrays
+    // under a kernel in flight.  At most one plan per block size is kept; a new size evicts the others from the table (they
+    // live on until their last user returns).  The residual skip index belongs to its plan and is published through
+    // Plan::skip_state (release / acquire).
+    std::map<uint32_t, std::shared_ptr<Plan>> plans; std::mutex mu; std::mutex skip_mu;
+    // cached shard bounds (bvg_shard_bounds): key = (k << 2) | balance
+    std::map<uint64_t, std::vector<int64_t>> shard_bounds; std::mutex shard_mu;
     std::atomic<int> refs{1};
 };
 
@@ -181,7 +196,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
 void release_shared(Shared* sh) {
     if (sh->refs.fetch_sub(1) != 1) return;
     (void)hipSetDevice(sh->device);
-    sh->plan.release();
+    sh->plans.clear();
     if (sh->own_graph && sh->d_graph) (void)hipFree(sh->d_graph);
     if (sh->own_offsets && sh->d_offsets) (void)hipFree(sh->d_offsets);
     delete sh;
@@ -195,14 +210,20 @@ int ensure_device(int device) {
 }
 
 // Builds the block plan: boundaries at ~equal compressed bits + per-block halo masks.
-int build_plan(bvg_graph* g, uint32_t block_bits) {
+int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
     Shared* sh = g->sh;
     std::lock_guard<std::mutex> lk(sh->mu);
-    if (sh->plan.nblk && sh->plan.block_bits == block_bits) return 0;
-    sh->plan.release();
-    sh->plan.block_bits = block_bits;
+    {
+        auto it = sh->plans.find(block_bits);
+        if (it != sh->plans.end()) { out = it->second; return 0; }
+    }
+    std::shared_ptr<Plan> np = std::make_shared<Plan>();
+    Plan& plan = *np;
+    plan.device = sh->device;
+    plan.block_bits = block_bits;
+    auto publish = [&]() { sh->plans.clear(); sh->plans[block_bits] = np; out = np; return 0; };
     const int64_t n = sh->p.nodes;
-    if (n == 0) { sh->plan.nblk = 0; sh->plan.h_first.assign(1, 0); return 0; }
+    if (n == 0) { plan.nblk = 0; plan.h_first.assign(1, 0); return publish(); }
     const uint64_t limit = sh->nbytes;
     uint64_t nb = (sh->total_bits + block_bits - 1) / block_bits;
     if (nb == 0) nb = 1;
@@ -235,21 +256,21 @@ int build_plan(bvg_graph* g, uint32_t block_bits) {
         for (uint32_t k = 0; k < nblk; k++) if (halo[k] == 0xFFFFFFFFu) { any_bad = true; break; }
         if (!any_bad || pass == 1) {
             if (any_bad) { (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask); return BVG_E_UNSUPPORTED; }
-            sh->plan.d_first = d_first; sh->plan.d_halo = d_halo; sh->plan.d_mask = d_mask;
-            sh->plan.nblk = nblk; sh->plan.h_first = uniq;
+            plan.d_first = d_first; plan.d_halo = d_halo; plan.d_mask = d_mask;
+            plan.nblk = nblk; plan.h_first = uniq;
             {   // per-block largest outdegree (one wavefront per block), kept on the host to predict tiers
                 uint32_t* d_maxd = nullptr;
                 HIPCHK(hipMalloc(&d_maxd, (size_t)nblk * sizeof(uint32_t)));
                 launch_plan_maxd(sh->d_graph, limit, sh->d_offsets, d_first, d_halo, nblk, sh->p.outdegree_coding, sh->p.window_size, d_maxd, g->stream);
-                sh->plan.h_maxd.resize(nblk);
-                hipError_t e2 = hipMemcpyAsync(sh->plan.h_maxd.data(), d_maxd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
+                plan.h_maxd.resize(nblk);
+                hipError_t e2 = hipMemcpyAsync(plan.h_maxd.data(), d_maxd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
                 if (e2 == hipSuccess) e2 = hipStreamSynchronize(g->stream);
                 (void)hipFree(d_maxd);
                 if (e2 != hipSuccess) return BVG_E_HIP;
             }
             static std::atomic<uint64_t> plan_versions{1};
-            sh->plan.version = plan_versions.fetch_add(1);
-            return 0;
+            plan.version = plan_versions.fetch_add(1);
+            return publish();
         }
         // merge blocks: drop un-cuttable boundaries (the halo of a kept boundary does not depend on the others)
         std::vector<uint64_t> kept; kept.reserve(uniq.size());
@@ -268,58 +289,60 @@ uint32_t block_bits_of(const bvg_graph* g) { return g->tun.block_bits ? g->tun.b
 struct BatchPlan { const uint64_t* d_first; const uint32_t* d_halo; const uint64_t* d_mask; uint32_t requests; };
 
 int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
-               bvg_scan_result* res, const BatchPlan* batch = nullptr);
+               bvg_scan_result* res, const BatchPlan* batch = nullptr, const std::shared_ptr<Plan>* use_plan = nullptr);
 
 // Residual skip index: nodes with long residual lists get one entry per kSkipEvery residuals, so the row kernel can decode a
 // long list as independent segments on otherwise idle lanes.  Two passes of the ordinary decode over the whole graph: count the
 // entries of every block, prefix-sum on the host, fill.  An index, not a cache: every gap is still decoded from the stream.
-int build_skip(bvg_graph* g) {
+int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp) {
     Shared* sh = g->sh;
     std::lock_guard<std::mutex> lk(sh->skip_mu);
-    Plan& pl = sh->plan;
-    if (pl.skip_state) return 0;
+    Plan& pl = *plp;
+    if (pl.skip_state.load(std::memory_order_acquire)) return 0;
     const uint32_t nblk = pl.nblk;
     const int64_t n = sh->p.nodes;
-    if (!nblk || n == 0) { pl.skip_state = 1; return 0; }
+    if (!nblk || n == 0) { pl.skip_state.store(1, std::memory_order_release); return 0; }
     const bool build_wide = sh->wide || g->tun.force_wide;
     uint32_t* d_cnt = nullptr;
     HIPCHK(hipMalloc(&d_cnt, (size_t)nblk * sizeof(uint32_t)));
     HIPCHK(hipMemset(d_cnt, 0, (size_t)nblk * sizeof(uint32_t)));
     g->skip_mode = 1; g->skip_cnt = d_cnt;
-    int r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr);
+    int r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_cnt = nullptr;
     std::vector<uint32_t> cnt(nblk);
     if (!r && hipMemcpy(cnt.data(), d_cnt, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
     (void)hipFree(d_cnt);
-    if (r) { pl.skip_state = 1; return 0; }                // a bad stream surfaces in the caller's own decode; no index then
+    if (r) { pl.skip_state.store(1, std::memory_order_release); return 0; }                // a bad stream surfaces in the caller's own decode; no index then
     std::vector<uint64_t> first(nblk + 1, 0);
     for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + cnt[i];
     const uint64_t total = first[nblk];
-    if (total == 0) { pl.skip_state = 1; return 0; }
+    if (total == 0) { pl.skip_state.store(1, std::memory_order_release); return 0; }
     if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&pl.d_skip_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; (void)hipGetLastError(); return 0; }
-    if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state = 1; return 0; }
+        hipMalloc(&pl.d_skip_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); (void)hipGetLastError(); return 0; }
+    if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
     pl.skip_total = total; pl.skip_wide = build_wide;
     g->skip_mode = 2;
-    r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr);
+    r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0;
-    if (r) { pl.release_skip(); pl.skip_state = 1; return 0; }
+    if (r) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
     pl.h_skip_first.swap(first);
-    pl.skip_state = 1;
+    pl.skip_state.store(1, std::memory_order_release);
     if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * (build_wide ? 12.0 : 8.0) / 1048576.0);
     return 0;
 }
 
 int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
-               bvg_scan_result* res, const BatchPlan* batch) {
+               bvg_scan_result* res, const BatchPlan* batch, const std::shared_ptr<Plan>* use_plan) {
     Shared* sh = g->sh;
     int r = 0;
     const bool force_slow = g->tun.force_slow || sh->p.window_size > kMaxWindow;   // wide windows: the generic global-memory kernel only
-    if (!batch) { r = build_plan(g, block_bits_of(g)); if (r) return r; }
+    static const std::shared_ptr<Plan> no_plan = std::make_shared<Plan>();         // batch calls bring their own per-call plan
+    std::shared_ptr<Plan> plp = use_plan ? *use_plan : no_plan;                     // held for the whole call (see Shared::plans)
+    if (!batch && !use_plan) { r = build_plan(g, block_bits_of(g), plp); if (r) return r; }
     const bool rows_default = (g->tun.reserved & 0xFF) == 0 && !force_slow;
-    if (!batch && rows_default && g->skip_mode == 0 && !sh->plan.skip_state && !getenv("BVG_NOSKIP") &&
-        (to - from) >= sh->p.nodes / 4 && (to - from) >= 4096) { r = build_skip(g); if (r) return r; }
-    const Plan& pl = sh->plan;
+    if (!batch && rows_default && g->skip_mode == 0 && !plp->skip_state.load(std::memory_order_acquire) && !getenv("BVG_NOSKIP") &&
+        (to - from) >= sh->p.nodes / 4 && (to - from) >= 4096) { r = build_skip(g, plp); if (r) return r; }
+    const Plan& pl = *plp;
     const bool wide = sh->wide || g->tun.force_wide;
     // block range
     uint32_t lo = 0, nblocks = 0;
@@ -359,7 +382,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         a.pass_cost = getenv("BVG_PASSCOST") ? (uint32_t)strtoul(getenv("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
-    if (!batch && rows_default && pl.skip_total && pl.skip_wide == wide && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state)) {
+    if (!batch && rows_default && pl.skip_total && pl.skip_wide == wide && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state.load(std::memory_order_acquire))) {
         a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val;
     }
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
@@ -1150,6 +1173,70 @@ int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) {
     if (e != hipSuccess) return BVG_E_HIP;
     for (int i = 0; i <= k; i++) bounds[i] = (int64_t)f[(size_t)i];
     bounds[0] = 0; bounds[k] = n;
+    return 0;
+}
+
+// Shard bounds of a k-way split of the node range (ImmutableGraph.splitNodeIterators, IG:405-436): BVG_BALANCE_NODES is the
+// reference's own rule (ceil(n/k) nodes each, IG:415-433), BVG_BALANCE_BITS / _ARCS the balanced variants above.  Cached per
+// (k, balance) in the shared part of the handle, so every flyweight and every later call agrees on them.
+int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds) {
+    if (!g || !bounds || k < 1 || balance < BVG_BALANCE_NODES || balance > BVG_BALANCE_ARCS) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    const uint64_t key = ((uint64_t)k << 2) | (uint64_t)balance;
+    std::lock_guard<std::mutex> lk(sh->shard_mu);
+    auto it = sh->shard_bounds.find(key);
+    if (it == sh->shard_bounds.end()) {
+        std::vector<int64_t> b((size_t)k + 1);
+        int r = 0;
+        if (balance == BVG_BALANCE_NODES) {
+            const int64_t n = sh->p.nodes, m = n ? (n + k - 1) / k : 0;
+            for (int i = 0; i <= k; i++) b[(size_t)i] = std::min<int64_t>((int64_t)i * m, n);
+        } else r = balance == BVG_BALANCE_BITS ? bvg_split_by_bits(g, k, b.data()) : bvg_split_by_arcs(g, k, b.data());
+        if (r) return r;
+        it = sh->shard_bounds.emplace(key, std::move(b)).first;
+    }
+    memcpy(bounds, it->second.data(), ((size_t)k + 1) * sizeof(int64_t));
+    return 0;
+}
+
+// Shard r of k: the scan of nodes [bounds[r], bounds[r+1]) (one rank of the multi-GPU scan; the caller reduces {arcs, chk}).
+int bvg_scan_shard(bvg_graph* g, int k, int r, int balance, bvg_scan_result* out, int64_t* from, int64_t* to) {
+    if (!g || !out || k < 1 || r < 0 || r >= k) return BVG_E_ARG;
+    std::vector<int64_t> b((size_t)k + 1);
+    int rc = bvg_shard_bounds(g, k, balance, b.data()); if (rc) return rc;
+    if (from) *from = b[(size_t)r];
+    if (to) *to = b[(size_t)r + 1];
+    return bvg_scan(g, b[(size_t)r], b[(size_t)r + 1], out);
+}
+
+// One process, several GPUs (what a JVM host has): handle i scans shard i of ngpu on its own device, all at once (one host
+// thread each), and the per-shard {nodes, arcs, chk} are summed on the host -- 24 bytes, so no device collective is involved
+// (the one-process-per-GPU form of the same reduction is bench.py's RCCL all-reduce).  The handles must describe the same graph
+// (replicas opened on different devices, or bvg_copy() flyweights on one device).  kernel_ms = the slowest shard.
+int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_result* total, bvg_scan_result* per_shard) {
+    if (!per_gpu || ngpu < 1 || !total) return BVG_E_ARG;
+    for (int i = 0; i < ngpu; i++) {
+        if (!per_gpu[i]) return BVG_E_ARG;
+        const bvg_params &a = per_gpu[0]->sh->p, &b = per_gpu[i]->sh->p;
+        if (a.nodes != b.nodes || a.arcs != b.arcs || per_gpu[0]->sh->total_bits != per_gpu[i]->sh->total_bits) return BVG_E_ARG;
+    }
+    std::vector<int64_t> bounds((size_t)ngpu + 1);
+    int rc = bvg_shard_bounds(per_gpu[0], ngpu, balance, bounds.data()); if (rc) return rc;
+    std::vector<bvg_scan_result> res((size_t)ngpu);
+    std::vector<int> st((size_t)ngpu, 0);
+    std::vector<std::thread> th;
+    for (int i = 0; i < ngpu; i++)
+        th.emplace_back([&, i] { st[(size_t)i] = bvg_scan(per_gpu[i], bounds[(size_t)i], bounds[(size_t)i + 1], &res[(size_t)i]); });
+    for (auto& t : th) t.join();
+    memset(total, 0, sizeof *total);
+    for (int i = 0; i < ngpu; i++) {
+        if (st[(size_t)i]) return st[(size_t)i];
+        const bvg_scan_result& x = res[(size_t)i];
+        total->nodes += x.nodes; total->arcs += x.arcs; total->chk += x.chk; total->graph_bytes += x.graph_bytes; total->index_bytes += x.index_bytes;
+        total->launches += x.launches; total->slow_blocks += x.slow_blocks;
+        if (x.kernel_ms > total->kernel_ms) total->kernel_ms = x.kernel_ms;
+        if (per_shard) per_shard[i] = x;
+    }
     return 0;
 }
 

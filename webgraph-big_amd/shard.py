@@ -40,3 +40,28 @@ def allreduce_max(value, device=None, group=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def bounds_by_arcs(outdeg, k):
+    """The rule of bvg_split_by_arcs on a host array of outdegrees: bounds[j] = first node whose cumulative outdegree (exclusive
+    prefix) reaches j * ceil(arcs / k) (the skipTo() targets of algo/HyperBall.java:748-768); bounds[0] = 0, bounds[k] = n."""
+    n = len(outdeg)
+    cum = np.concatenate([[0], np.cumsum(np.asarray(outdeg, dtype=np.int64))]).astype(np.uint64)
+    arcs = int(cum[-1])
+    per = max(1, -(-arcs // k))
+    b = np.searchsorted(cum[:n + 1], np.arange(k + 1, dtype=np.uint64) * np.uint64(per), side="left").astype(np.int64)
+    b = np.minimum(b, n)
+    b[0] = 0; b[k] = n
+    return b
+
+
+def sharded_scan(scan_range, bounds, rank, device=None, group=None, reduce=True):
+    """One rank of the strong-scaling scan of ONE graph: this rank scans nodes [bounds[rank], bounds[rank+1]) with
+    scan_range(lo, hi) -> {'arcs', 'chk', ...} (the HIP handle's scan on a GPU box, the oracle in the CPU tests) and the
+    per-shard {arcs, chk} are summed over all ranks -- the path's only collective.  Returns (own result, arcs, chk)."""
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    r = scan_range(lo, hi)
+    if not reduce:
+        return r, int(r["arcs"]), int(r["chk"])
+    arcs, chk = allreduce_scan(r["arcs"], r["chk"], device=device, group=group)
+    return r, arcs, chk

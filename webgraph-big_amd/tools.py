@@ -142,6 +142,34 @@ def synth_store(n, seed=0, params=None, synth=None, chunk_nodes=1 << 16, threads
     return Stored(p, _take(g, gb.value), _take(o, 8 * (n + 1), np.uint64), st.as_dict())
 
 
+def tile_host(st, copies):
+    """Host twin of bvg_tile: `copies` back-to-back copies of a stored graph as one Stored (BV records are translation invariant,
+    SURVEY A.3: copy j is the base graph shifted by j * nodes).  Used to give the CPU baseline a stream of realistic size."""
+    base = np.ascontiguousarray(st.graph, dtype=np.uint8)
+    nbits = int(st.offsets[-1])
+    total = nbits * copies
+    out = np.zeros((total + 7) // 8 + 2, dtype=np.uint8)
+    nb = (nbits + 7) // 8
+    src = base[:nb].copy()
+    if nbits & 7:
+        src[-1] &= np.uint8((0xFF << (8 - (nbits & 7))) & 0xFF)          # padding bits of the last byte must stay clear
+    for j in range(copies):
+        o = j * nbits; b0 = o >> 3; sh = o & 7
+        if sh == 0:
+            out[b0:b0 + nb] |= src
+        else:
+            out[b0:b0 + nb] |= src >> np.uint8(sh)
+            out[b0 + 1:b0 + 1 + nb] |= (src << np.uint8(8 - sh)) & np.uint8(0xFF)
+    n = int(st.params.nodes)
+    offs = np.empty(n * copies + 1, dtype=np.uint64)
+    for j in range(copies):
+        offs[j * n:(j + 1) * n] = st.offsets[:n] + np.uint64(j * nbits)
+    offs[-1] = total
+    p = st.params.clone(nodes=n * copies, arcs=int(st.stats["arcs"]) * copies)
+    stats = dict(st.stats); stats["arcs"] = int(st.stats["arcs"]) * copies
+    return Stored(p, out[:(total + 7) // 8], offs, stats)
+
+
 def synth_adjacency(n, seed=0, synth=None, chunk_nodes=1 << 16):
     sp = synth or web_like()
     po = C.c_void_p(); pa = C.c_void_p()
