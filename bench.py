@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-gib", type=float, default=1.0, help="size of the stream the CPU baseline scans")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-tile checksum gate against the CPU oracle")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on a one-GPU box)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -73,14 +75,19 @@ def main():
     import webgraph_big_amd as W
     from webgraph_big_amd import tools as T, shard as S
 
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if launched:                                                         # the process group exists whenever a launcher set the env
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     dev = local_rank
-    cuda = torch.device("cuda", local_rank)
+    cuda = torch.device("cuda", local_rank) if args.backend == "nccl" else None   # where the collective's 16 bytes live
 
     # ---- synthetic input: generate + compress on the host, upload, tile on the device ----
     t0 = time.time()
