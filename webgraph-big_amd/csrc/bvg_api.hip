@@ -475,8 +475,21 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // resident waves per CU step down with the LDS footprint: take every byte of the step the pool lands on
                 const uint64_t lds_cu = 160 * 1024, fixed = (uint64_t)a.lds_stage_words * 4 + 1536 + 256;   // window + static arrays (+ slack)
                 auto foot = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed + 1023) & ~1023ull; };
-                const uint64_t waves = std::max<uint64_t>(1, lds_cu / foot(pool));
-                while (pool + 64 <= (wide ? 4096u : 8192u) && lds_cu / foot(pool + 64) == waves) pool += 64;
+                uint64_t waves = std::max<uint64_t>(1, lds_cu / foot(pool));
+                // Two wavefronts per SIMD (8 per CU) is the step that pays on dense graphs: below it the CU's SIMDs sit idle behind
+                // LDS latency, and a row that shrinks to ~40 lists costs less than the lost wavefronts (eu15 shape, 4 GiB: 90.0 G
+                // edges/s at 6 per CU with 54 lists per row, 98.7 G at 8 per CU with 43; profiles/r02/occ_sweep15.sh).
+                if (waves < 8 && !getenv("BVG_STAGE")) {
+                    uint64_t p8 = pool;
+                    const uint32_t st8 = std::min<uint32_t>(a.lds_stage_words, 512);
+                    const uint64_t fixed8 = (uint64_t)st8 * 4 + 1536 + 256;
+                    auto foot8 = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed8 + 1023) & ~1023ull; };
+                    while (p8 > 1024 && lds_cu / foot8(p8) < 8) p8 -= 64;
+                    if ((double)p8 >= 40.0 * avg && lds_cu / foot8(p8) >= 8) { pool = p8; a.lds_stage_words = st8; waves = lds_cu / foot8(p8); }
+                }
+                const uint64_t fixed2 = (uint64_t)a.lds_stage_words * 4 + 1536 + 256;
+                auto foot2 = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed2 + 1023) & ~1023ull; };
+                while (pool + 64 <= (wide ? 4096u : 8192u) && lds_cu / foot2(pool + 64) == waves) pool += 64;
             }
             if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
@@ -656,14 +669,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     }
     if (d_work) (void)hipFree(d_work);
 
-    unsigned long long acc[20];
+    unsigned long long acc[24];
     launch_reduce_acc(g->d_acc, kAccStripes, g->stream);
     HIPCHK(hipMemcpyAsync(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
-    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: position steps %llu, position passes %llu, extras passes %llu, rows %llu, position tasks %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7]);
+    if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: position steps %llu, position passes %llu, extras passes %llu, rows %llu, position tasks %llu, leaf steps %llu, leaf passes %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[22], acc[23]);
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
-        fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6);
+        fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f; leaf pass %.0f (loop %.0f)\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6, acc[20] / 1e6, acc[21] / 1e6);
     }
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];

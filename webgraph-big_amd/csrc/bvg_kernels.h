@@ -14,6 +14,10 @@ namespace bvg {
 #ifndef BVG_SKIP_EVERY
 #define BVG_SKIP_EVERY 16
 #endif
+#ifndef BVG_RES_UNROLL
+#define BVG_RES_UNROLL 2
+#endif
+constexpr uint32_t kResUnroll = BVG_RES_UNROLL;   // residual segments decoded per lane and pass, interleaved (row kernel)
 constexpr uint32_t kShortTask = 6;   // residual tails this short are dealt after the long tasks of the row
 constexpr uint32_t kSkipMin = BVG_SKIP_MIN, kSkipEvery = BVG_SKIP_EVERY;   // residual skip index granularity (kSkipEvery: a power of two)
 constexpr uint32_t kAccStripes = 2048, kAccStride = 32;   // result stripes (power of two), 256 bytes apart (stripe 0 also carries 16 debug counters)

@@ -23,11 +23,14 @@
 // global-memory kernel in bvg_kernels.hip).
 #include "bvg_rows_common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 #ifndef BVG_ROWS_WAVES
 #define BVG_ROWS_WAVES 6
 #endif
 #ifndef BVG_TASK_WAVES
-#define BVG_TASK_WAVES 5
+#define BVG_TASK_WAVES 4
 #endif
 
 namespace bvg {
@@ -41,8 +44,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint32_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
-    __shared__ uint32_t rtmap[64];                // residual segments -> lanes (skip index)
-    __shared__ uint32_t produced[64];             // read/written with wavefront-scope relaxed atomics: plain ds_read/ds_write that
+    __shared__ uint32_t rtmap[64 * (kResUnroll > 2 ? kResUnroll : 2)];   // residual segments -> lanes (skip index): kResUnroll tasks per lane and pass
+    uint32_t* const produced = rtmap + 64;        // (phase 2 only: the residual tasks of phase 1 are done by then)             // read/written with wavefront-scope relaxed atomics: plain ds_read/ds_write that
                                                   // the compiler may not cache (a `volatile` here compiles to flat sc0 sc1 + vmcnt(0))
 
     const unsigned lane = threadIdx.x;
@@ -76,12 +79,12 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     unsigned err = 0;
     bool failed = false;
     uint32_t fail_need = 0xFFFFFFFFu;                        // pool elements that would have been enough (when known)
-    uint32_t cnt_iter = 0, cnt_pass = 0, cnt_rows = 0, cnt_tasks = 0, cnt_seek = 0;   // BVG_DBG & 64: work counters (wave-uniform)
+    uint32_t cnt_iter = 0, cnt_pass = 0, cnt_rows = 0, cnt_tasks = 0, cnt_seek = 0, cnt_leaf = 0, cnt_leafp = 0;   // BVG_DBG & 64: work counters (wave-uniform)
     // -DBVG_PROF builds only (`make prof`): wave-cycles per section {row prep, level prep, task set-up, seeks, merge loop,
     // phase 1, row set-up, headers, pool sizing, residuals}, reported with BVG_DBG & 64.  Off by default: the accumulators cost
     // registers.  Wave-cycles measure latency, not issue slots: sections that other resident waves overlap look larger than they cost.
 #ifdef BVG_PROF
-    uint32_t cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // a block lives well under 2^32 cycles
+    uint32_t cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // a block lives well under 2^32 cycles
 #define BVG_T0() ((uint32_t)clock64())
 #define BVG_T1(i, t) do { cyc[i] += (uint32_t)clock64() - (t); } while (0)
 #else
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         // Steps A..D with two wave-uniform points where the scratch area (copy blocks, then intervals) is
         // allocated by prefix sums; lanes whose entries do not fit are cut from the row (k shrinks) and
         // their nodes are simply parsed again at the head of the next row.
-        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
+        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0, ivtot = 0;
         int64_t extra = d;
         bool malf = false;                                                   // counts that contradict each other (position tasks need them exact)
         const bool parse = needed && lane < k && d > 0 && !(a.dbg & 4);
@@ -253,7 +256,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
                     const int64_t len = (int64_t)v2 + minint;
                     prev = leftv + len;
-                    extra -= len;
+                    extra -= len; ivtot += (uint32_t)len;
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
                 if (extra < 0) { err |= ERR_MALFORMED; extra = 0; malf = true; }
@@ -335,41 +338,81 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             const uint64_t smask = ballot(shortt);
             const uint32_t ss = NL + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull)), Ttot = NL + (uint32_t)__popcll(smask);
             bool tbad = false;
-            for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+            // RU tasks per lane and pass, decoded in one interleaved loop: a gap is a chain of dependent LDS reads and shifts
+            // (~300 cycles), and with two wavefronts per SIMD nothing else hides it -- two independent chains per lane do.
+            constexpr uint32_t RU = kResUnroll, RP = 64u * RU;
+            for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
                 {
                     const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
-                    const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
+                    const uint32_t q1 = ts >= p0 + RP ? 0u : (ts + Tn > p0 + RP ? p0 + RP - ts : Tn);
                     for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
-                    if (shortt && ss >= p0 && ss < p0 + 64u) rtmap[ss - p0] = lane | (cntE << 8);
+                    if (shortt && ss >= p0 && ss < p0 + RP) rtmap[ss - p0] = lane | (cntE << 8);
                 }
                 __syncthreads();
-                const bool tl = p0 + lane < Ttot;
-                const uint32_t ent = tl ? rtmap[lane] : lane;
-                const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
-                const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
-                const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(rdst, nl, 64), t_ef = __shfl(efirst, nl, 64);
-                if (tl) {
+                bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tlast[RU]; T r[RU];
+#pragma unroll
+                for (uint32_t u = 0; u < RU; u++) {
+                    tl[u] = p0 + 64u * u + lane < Ttot;
+                    const uint32_t ent = tl[u] ? rtmap[64u * u + lane] : lane;
+                    const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                    const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
+                    const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(rdst, nl, 64), t_ef = __shfl(efirst, nl, 64);
                     const uint32_t t0 = q * kSkipEvery;
                     const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
-                    const uint32_t cnt = q == t_ce ? t_nres - t0 : kSkipEvery;            // the last segment takes the remainder
-                    uint32_t trel = t_rel; T r = (T)(r0 + nl);
-                    if (q) {
+                    cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
+                    trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)(r0 + nl); tpend[u] = t_pend;
+                    tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
+                    tlast[u] = (tl[u] && t0 + cnt[u] == t_nres) ? 1u : 0u;
+                    taddr[u] = t_dst + t0;
+                    if (tl[u] && q) {
                         const uint64_t e = sk_base + t_ef + q - 1u;
-                        trel = t_rec + a.skip_bit[e]; r = reinterpret_cast<const T*>(a.skip_val)[e];
-                        if (!(trel > t_rel && trel < t_pend)) tbad = true;
+                        trel[u] = t_rec + a.skip_bit[e]; r[u] = reinterpret_cast<const T*>(a.skip_val)[e];
+                        if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
                     }
-                    T* const tail = pool + t_dst + t0;
-                    for (uint32_t i = 0; i < cnt && !tbad; i++) {
-                        uint64_t val;
-                        const uint32_t len = read_residual<GEN>(stage, trel, zfast, zk, a.cod.residual, val);
-                        if (len == 0) { tbad = true; break; }
-                        trel += len;
-                        r = (t0 + i) == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
-                        tail[i] = r;
-                        if (trel > t_pend) { err |= ERR_OVERRUN; break; }
-                    }
-                    if (t0 + cnt == t_nres && trel != t_pend && !tbad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
                 }
+                auto decode_tasks = [&](auto ZF) {                            // ZF: the 32-bit zeta fast path is compiled in (no test inside the loop)
+                    for (uint32_t i = 0;; i++) {
+                        bool on[RU]; bool any = false;
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) { on[u] = i < cnt[u]; any |= on[u]; }
+                        if (!ballot(any)) break;
+                        uint32_t len[RU]; uint64_t val[RU]; bool slow = false;
+                        uint32_t w32[RU];
+                        if (decltype(ZF)::value) {
+#pragma unroll
+                            for (uint32_t u = 0; u < RU; u++) w32[u] = win32<LIN>(stage, trel[u]);   // all chains' LDS reads first: they overlap
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) {
+                            len[u] = 0; val[u] = 0;
+                            if (decltype(ZF)::value) { uint32_t v32; len[u] = zeta_fast32(w32[u], zk, v32); val[u] = v32; }
+                            slow |= on[u] && len[u] == 0;
+                        }
+                        if (ballot(slow)) {                                   // codes longer than 31 bits / other codings: one rare, wave-uniform detour
+#pragma unroll
+                            for (uint32_t u = 0; u < RU; u++)
+                                if (on[u] && len[u] == 0) {
+                                    const uint64_t w = win64<LIN>(stage, trel[u]);
+                                    len[u] = GEN ? decode_generic_w(w, a.cod.residual, zk, &val[u]) : zeta64(w, zk, val[u]);
+                                    if (len[u] == 0) { tbad = true; cnt[u] = 0; on[u] = false; }
+                                }
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) {
+                            const T gap = (tfirst[u] && i == 0) ? (T)nat2int64(val[u]) : (T)(1 + (T)val[u]);
+                            const T rn = (T)(r[u] + gap);
+                            const uint32_t tn = trel[u] + len[u];
+                            if (on[u]) pool[taddr[u] + i] = rn;
+                            r[u] = on[u] ? rn : r[u]; trel[u] = on[u] ? tn : trel[u];
+                            const bool over = on[u] && tn > tpend[u];
+                            err |= over ? ERR_OVERRUN : 0u; cnt[u] = over ? 0u : cnt[u]; tlast[u] = over ? 0u : tlast[u];
+                        }
+                    }
+                };
+                if (zfast) decode_tasks(std::true_type{}); else decode_tasks(std::false_type{});
+#pragma unroll
+                for (uint32_t u = 0; u < RU; u++)
+                    if (tlast[u] && cnt[u] && trel[u] != tpend[u] && !tbad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
                 __syncthreads();
             }
             if (((act && d == 0) || (parse && lane < k && nres == 0)) && rel != pend && !bad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
@@ -530,18 +573,19 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 }
                 BVG_T1(3, tq1);
                 const uint32_t tq1b = BVG_T0();
-                // ---------------- Z2: tasks of S output positions
-                const uint32_t Wl = wave_sum32(mem ? d : 0u);
+                // ---------------- Z2: tasks of S output positions (lists that some later node may copy; the others wait for the leaf pass)
+                const bool mem2 = mem && stored;
+                const uint32_t Wl = wave_sum32(mem2 ? d : 0u);
                 uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
                 uint32_t Tn = 0;
                 for (int it = 0; it < 6; it++) {
                     Tn = 0;
-                    if (mem) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
+                    if (mem2) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
                     const uint32_t tt = wave_sum32(Tn);
                     if (tt <= 64u || it == 5) break;
                     const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
                     S = s2 > S ? s2 : S + 1u;
-                }
+                    }
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
                 BVG_T1(1, tq1b);
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
@@ -613,6 +657,83 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     BVG_T1(4, tq4);
                 }
             }
+            // ---------------- leaf pass (scan mode): lists that no later node copies are never materialised, so they need no
+            // output positions at all -- their residuals were summed by Z1, and what is left is to sum the kept elements of the
+            // referenced list (MaskedLongIterator.java:73-100) and the interval elements, in equal tasks of S elements over ALL
+            // such nodes of the row at once (every referenced list is complete by now).
+            const uint32_t tqL = BVG_T0();
+            if (LEAN && by_tasks && ballot(emitn && !stored)) {
+                const bool lf = emitn && !stored && !zbad;
+                const uint32_t keptN = lf ? (pure ? nres : d - nres - ivtot) : 0u;      // copied elements (the parked residuals of a reference-free node)
+                const uint32_t ivN = lf ? ivtot : 0u;
+                const uint32_t Wk = wave_sum32(keptN + ivN);
+                uint32_t S = (Wk + 63u) >> 6; if (S < kMinTask) S = kMinTask;
+                uint32_t Tk = 0, Tn = 0;
+                for (int it = 0; it < 6; it++) {                               // the smallest S for which the tasks fit one pass
+                    Tk = (keptN + S - 1u) / S; Tn = Tk + (ivN + S - 1u) / S;
+                    const uint32_t tt = wave_sum32(Tn);
+                    if (tt <= 64u || it == 5) break;
+                    const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
+                    S = s2 > S ? s2 : S + 1u;
+                }
+                const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+                for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+                    {
+                        const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
+                        const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
+                        for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
+                    }
+                    __syncthreads();
+                    const bool tl = p0 + lane < Ttot;
+                    const uint32_t ent = tl ? tmap[lane] : lane;
+                    const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                    const uint32_t t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64), t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64);
+                    const uint32_t t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64), t_kept = __shfl(keptN, nl, 64), t_tk = __shfl(Tk, nl, 64), t_iv = __shfl(ivN, nl, 64);
+                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1r = __shfl(rep ? k1 : 0u, nl, 64);     // a node outside [from,to) sums nothing
+                    const T* const rl = pool + t_rlb;
+                    uint32_t cnt = 0, qcur = 0, krem = kInf, bi = t_bc, ivk = 0, ivrem = 0; bool iota = false; T ivv = 0;
+                    if (tl) {
+                        if (q < t_tk) {                                        // S kept elements from the t-th on
+                            const uint32_t t = q * S;
+                            cnt = t_kept - t < S ? t_kept - t : S;
+                            MaskPrefix<T>::select(scr + t_sb, t_bc, t_rlen, t, qcur, krem, bi);
+                        } else {                                               // S elements of the node's intervals, taken as one sequence
+                            uint32_t e0 = (q - t_tk) * S; iota = true;        // (LongIntervalSequenceIterator.java:71-78)
+                            cnt = t_iv - e0 < S ? t_iv - e0 : S;
+                            for (; ivk < t_ic; ivk++) {
+                                const uint32_t ln = (uint32_t)(scr[t_ib + 2 * ivk + 1] & HM);
+                                if (e0 < ln) { ivv = (T)(scr[t_ib + 2 * ivk] + (T)e0); ivrem = ln - e0; break; }
+                                e0 -= ln;
+                            }
+                        }
+                    }
+                    const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
+                    uint64_t csum = 0;
+                    const uint32_t tqL2 = BVG_T0();
+                    cnt_leafp++;
+                    for (uint32_t i = 0;; i++) {
+                        const bool todo = i < cnt;
+                        if (!ballot(todo)) break;
+                        cnt_leaf++;
+                        const T cv = rl[qcur < rlast ? qcur : rlast];
+                        const T v = iota ? ivv : cv;
+                        csum += mix_node<T>(t_k0, todo ? t_k1r : 0u, v, nb_lo, nbz);
+                        if (todo) {
+                            if (iota) {
+                                ivv++;
+                                if (--ivrem == 0 && ++ivk < t_ic) { ivv = scr[t_ib + 2 * ivk]; ivrem = (uint32_t)(scr[t_ib + 2 * ivk + 1] & HM); }
+                            } else {
+                                qcur++;
+                                if (--krem == 0) MaskPrefix<T>::next_block(scr + t_sb, t_bc, t_rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
+                            }
+                        }
+                    }
+                    blk_chk += csum;
+                    BVG_T1(11, tqL2);
+                    __syncthreads();
+                }
+            }
+            BVG_T1(10, tqL);
             if (by_tasks) {
                 if (ballot(zbad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
                 if (rep) { blk_arcs += d; blk_nodes += 1; }
@@ -720,8 +841,10 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         if (a.dbg & 64u) {
             atomicAdd(&a.acc[4], (unsigned long long)cnt_iter); atomicAdd(&a.acc[5], (unsigned long long)cnt_pass); atomicAdd(&a.acc[6], (unsigned long long)cnt_rows);
             atomicAdd(&a.acc[7], (unsigned long long)cnt_tasks); atomicAdd(&a.acc[8], (unsigned long long)cnt_seek);
+            atomicAdd(&a.acc[22], (unsigned long long)cnt_leaf); atomicAdd(&a.acc[23], (unsigned long long)cnt_leafp);
 #ifdef BVG_PROF
             for (int i = 0; i < 10; i++) atomicAdd(&a.acc[9 + i], (unsigned long long)cyc[i]);
+            atomicAdd(&a.acc[20], (unsigned long long)cyc[10]); atomicAdd(&a.acc[21], (unsigned long long)cyc[11]);
 #endif
         }
     }
@@ -734,7 +857,8 @@ void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     dim3 grid(nblocks), block(64);
     const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
-    const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (size_t)a.lds_stage_words * 4;
+    size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (size_t)a.lds_stage_words * 4;
+    if (getenv("BVG_LDSPAD")) dyn += (size_t)atoi(getenv("BVG_LDSPAD"));   // occupancy experiments: unused LDS behind the window
     const bool task = a.emit_tasks != 0;
 #define BVG_RL(T, M) do { if (task) { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, true>), grid, block, dyn, s, a); \
                                       else hipLaunchKernelGGL((rows_kernel<T, M, false, true>), grid, block, dyn, s, a); } \

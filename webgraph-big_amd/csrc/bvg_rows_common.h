@@ -45,6 +45,21 @@ template <bool GEN> __device__ __forceinline__ uint32_t read_residual(const uint
     return len;
 }
 
+// zeta_k from a 32-bit window (k >= 2): returns the code length, 0 = the code does not fit 31 bits.  Straight-line (selects
+// only), so several independent decodes interleave in one instruction stream.
+__device__ __forceinline__ uint32_t zeta_fast32(uint32_t w, uint32_t zk, uint32_t& val) {
+    const uint32_t z = w ? (uint32_t)__builtin_clz(w) : 32u;
+    const uint32_t nbz = z * zk + zk - 1, zt = z + 1 + nbz;
+    const uint32_t fits = zt < 32 ? 1u : 0u, fm = 0u - fits;                    // masks instead of ?: so the compiler keeps it straight-line
+    const uint32_t nb = (nbz & fm) | (1u & ~fm), zz = z & fm;                    // every shift amount stays in range
+    const uint32_t tt = (w << (zz + 1)) >> (32u - nb);
+    const uint32_t leftv = 1u << (zz * zk);
+    const uint32_t shortc = tt < leftv ? 1u : 0u, sm = 0u - shortc;
+    const uint32_t ext = ((tt << 1) | ((w >> (31u - (zt & fm))) & 1u)) - 1u;
+    val = ((tt + leftv - 1u) & sm) | (ext & ~sm);
+    return (zt + 1u - shortc) & fm;
+}
+
 // Copy blocks in PREFIX form for the position tasks: entry i = (end position of block i in the referenced list) |
 // (kept elements up to and including block i) << HS, so both directions of the copy mask (MaskedLongIterator.java:67-128) are
 // binary searches instead of walks over up to hundreds of blocks: rank of a list position among the kept ones, and the
