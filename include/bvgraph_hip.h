@@ -119,6 +119,12 @@ int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out);
 int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Same, successor / outdegree buffers in device memory (stay in HBM for a downstream kernel). */
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ);
+/* Page-locked host memory for the buffers handed to bvg_decode_range / bvg_successors_batch: device -> host copies into it run
+ * at the PCIe rate and need no staging (a JNI caller wraps it in a direct ByteBuffer, NewDirectByteBuffer).  Plain malloc'ed /
+ * Java-heap buffers work too, only slower.  The iterator's buffer of NodeIterator.successorBigArray() (NodeIterator.java:80-96)
+ * is the intended use: one pair of buffers per iterator, reused batch after batch. */
+void* bvg_host_alloc(size_t bytes);
+void bvg_host_free(void* p);
 /* successors(x) for a whole frontier at once (BVG:860-867 per element; the access pattern of
  * algo/ParallelBreadthFirstVisit.java and algo/HyperBall.java:774-822): nodes[count] in any order, repeats
  * allowed; outdeg[count] and the successor lists concatenated in request order.  Each request is

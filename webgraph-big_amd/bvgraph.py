@@ -114,6 +114,8 @@ def lib():
         L.bvg_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
         L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_host_alloc.argtypes = [C.c_size_t]; L.bvg_host_alloc.restype = vp
+        L.bvg_host_free.argtypes = [vp]; L.bvg_host_free.restype = None
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
         L.bvg_split_by_arcs.argtypes = [vp, C.c_int, vp]
         L.bvg_shard_bounds.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -189,8 +191,89 @@ class LazyLongIterator:
             yield v
 
 
+class PinnedArray:
+    """A numpy view over page-locked host memory (bvg_host_alloc): device -> host copies into it run at the PCIe rate."""
+
+    def __init__(self, count, dtype):
+        self.dtype = np.dtype(dtype)
+        self.nbytes = max(int(count), 1) * self.dtype.itemsize
+        self._p = lib().bvg_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("bvg_host_alloc(%d)" % self.nbytes)
+        self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(self.nbytes,)).view(self.dtype)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            lib().bvg_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_PIN_CACHE = {}          # nbytes -> [PinnedArray]: page-locking memory costs ~0.3 s per GiB, so iterators hand their buffers on
+_PIN_CACHE_LIMIT = 8 << 30
+_pin_cached = 0
+
+
+def _pinned(count, dtype):
+    global _pin_cached
+    nbytes = max(int(count), 1) * np.dtype(dtype).itemsize
+    lst = _PIN_CACHE.get(nbytes)
+    if lst:
+        pa = lst.pop(); _pin_cached -= nbytes
+        pa.dtype = np.dtype(dtype)
+        pa.array = np.ctypeslib.as_array(C.cast(pa._p, C.POINTER(C.c_uint8)), shape=(nbytes,)).view(pa.dtype)
+        return pa
+    return PinnedArray(count, dtype)
+
+
+def _unpin(pa):
+    global _pin_cached
+    if pa is None or not getattr(pa, "_p", None):
+        return
+    if _pin_cached + pa.nbytes <= _PIN_CACHE_LIMIT:
+        _PIN_CACHE.setdefault(pa.nbytes, []).append(pa); _pin_cached += pa.nbytes
+    else:
+        pa.close()
+
+
+class _BatchSlot:
+    """One of the two batch buffers of a NodeIterator: a flyweight handle of its own (so the decode of the next batch can run on
+    another host thread, ImmutableGraph.java:187-197) and page-locked outdegree / successor buffers that are reused."""
+
+    def __init__(self, graph, batch_nodes):
+        self.g = graph.copy()
+        self.deg = _pinned(batch_nodes, np.int32)
+        self.succ = _pinned(max(1024, 32 * batch_nodes), np.int64)
+        self.lo = self.hi = 0
+        self.n_succ = 0
+
+    def decode(self, lo, hi):
+        need = C.c_uint64(0)
+        while True:
+            st = lib().bvg_decode_range(self.g._h, lo, hi, self.deg.array.ctypes.data, self.succ.array.ctypes.data, len(self.succ.array), C.byref(need))
+            if st == _abi.E_CAPACITY:
+                _unpin(self.succ)
+                self.succ = _pinned(((int(need.value) + int(need.value) // 4) + 0xFFFFF) & ~0xFFFFF, np.int64)
+                continue
+            _check(st, "decode_range(%d,%d)" % (lo, hi))
+            break
+        self.lo, self.hi, self.n_succ = lo, hi, int(need.value)
+        return self
+
+    def close(self):
+        _unpin(self.deg); _unpin(self.succ); self.deg = self.succ = None; self.g.close()
+
+
 class NodeIterator:
-    """BVGraph.BVGraphNodeIterator (BVGraph.java:1100-1245) fed by batched GPU decodes."""
+    """BVGraph.BVGraphNodeIterator (BVGraph.java:1100-1245) fed by batched GPU decodes.  Two batch slots: while the caller walks
+    batch i, a helper thread decodes batch i+1 (kernels + device -> host copy into page-locked memory) through a flyweight of
+    the graph, so the PCIe transfer and the decode overlap with the consumer."""
 
     def __init__(self, graph, frm, upper_bound=None, batch_nodes=None):
         n = graph.num_nodes()
@@ -203,20 +286,54 @@ class NodeIterator:
         self._batch_nodes = batch_nodes or graph.iterator_batch_nodes
         self._b0 = frm; self._b1 = frm
         self._deg = None; self._cum = None; self._succ = None
+        self._slots = None; self._pending = []; self._pool = None; self._held = None; self._free = []
 
     def has_next(self):
         return self._curr < self._limit                                                # BVG:1179-1181
 
     hasNext = has_next
 
+    _DEPTH = int(os.environ.get("BVG_ITER_DEPTH", "2"))                                                                         # batches decoded ahead of the caller
+
+    def _start(self):
+        import concurrent.futures
+        bn = max(1, min(self._batch_nodes, self._limit + 1 - self._from))
+        nb = -(-(self._limit + 1 - self._from) // bn)
+        depth = max(0, min(self._DEPTH, nb - 1))
+        self._slots = [_BatchSlot(self._g, bn) for _ in range(depth + 1)]
+        self._free = list(range(depth + 1))
+        self._pending = []                                                             # [(future, first node, slot index)], in node order
+        self._held = None
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, depth)) if depth else None
+
     def _fill(self, x):
-        hi = min(x + self._batch_nodes, self._limit + 1)
-        deg, succ = self._g.decode_range(x, hi)
-        self._b0, self._b1 = x, hi
-        self._deg = deg
-        self._cum = np.zeros(len(deg) + 1, dtype=np.int64)
-        np.cumsum(deg, out=self._cum[1:])
-        self._succ = succ
+        if self._slots is None:
+            self._start()
+        if self._held is not None:                                                     # the batch the caller has left: its buffers may be reused
+            self._free.append(self._held); self._held = None
+        slot = None
+        while self._pending:
+            fut, plo, si = self._pending.pop(0)
+            got = fut.result()                                                         # (raises what the decode raised)
+            if plo == x:
+                slot = got; self._held = si
+                break
+            self._free.append(si)                                                      # the caller jumped elsewhere: drop what was decoded ahead
+        if slot is None:
+            si = self._free.pop()
+            slot = self._slots[si].decode(x, min(x + self._batch_nodes, self._limit + 1)); self._held = si
+        # keep the pipeline full: the batches behind this one are decoded (kernels + device -> host copy) by helper threads, each
+        # through its own flyweight handle and stream, so one batch's copy overlaps the next one's kernels
+        nxt = self._pending[-1][1] + self._batch_nodes if self._pending else slot.hi
+        while self._pool is not None and self._free and nxt <= self._limit:
+            si = self._free.pop()
+            self._pending.append((self._pool.submit(self._slots[si].decode, nxt, min(nxt + self._batch_nodes, self._limit + 1)), nxt, si))
+            nxt += self._batch_nodes
+        self._b0, self._b1 = slot.lo, slot.hi
+        self._deg = slot.deg.array[:slot.hi - slot.lo]
+        self._cum = np.zeros(len(self._deg) + 1, dtype=np.int64)
+        np.cumsum(self._deg, out=self._cum[1:])
+        self._succ = slot.succ.array[:slot.n_succ]
 
     def next_long(self):
         if not self.has_next():
@@ -248,6 +365,17 @@ class NodeIterator:
 
     successorBigArray = successor_array
 
+    def batch(self):
+        """The whole current batch at once: (first node, outdeg int32[], cum int64[], succ int64[]) — views valid until the next
+        next_long() that leaves the batch (what a bulk consumer walks instead of one node at a time)."""
+        self._require_started()
+        return self._b0, self._deg, self._cum, self._succ
+
+    def skip_batch(self):
+        """Moves to the last node of the current batch (the next next_long() fetches the following batch)."""
+        self._require_started()
+        self._curr = self._b1 - 1
+
     def successors(self):
         return LazyLongIterator(self.successor_array())
 
@@ -261,6 +389,27 @@ class NodeIterator:
         while k < n and self.has_next():
             self.next_long(); k += 1
         return k
+
+    def close(self):
+        for fut, _, _ in self._pending:
+            try:
+                fut.result()
+            except Exception:
+                pass
+        self._pending = []
+        if self._pool is not None:
+            self._pool.shutdown(wait=True); self._pool = None
+        if self._slots is not None:
+            for sl in self._slots:
+                sl.close()
+            self._slots = None
+        self._deg = self._cum = self._succ = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BVGraph:

@@ -105,6 +105,7 @@ struct bvg_graph {
     static constexpr int kSide = 5;            // [0] giants (global-memory kernel), [1..4] one per LDS size class
     hipStream_t side[kSide] = {}; hipEvent_t side_ev[kSide] = {};
     void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
+    void* dr_ws = nullptr; size_t dr_ws_bytes = 0;   // bvg_decode_range / bvg_successors_batch workspace, kept between calls (grown on demand)
     void* tr_ws = nullptr; size_t tr_ws_bytes = 0;   // bvg_transpose workspace, kept between calls
     size_t tr_o_cum = 0, tr_o_succ = 0;             // where the last transpose left the graph's own CSR in it (bvg_symmetrize)
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
@@ -879,6 +880,7 @@ void bvg_close(bvg_graph* g) {
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->tr_ws) (void)hipFree(g->tr_ws);
+    if (g->dr_ws) (void)hipFree(g->dr_ws);
     if (g->d_acc) (void)hipFree(g->d_acc);
     if (g->d_fail) (void)hipFree(g->d_fail);
     if (g->slow_ws) (void)hipFree(g->slow_ws);
@@ -914,6 +916,21 @@ int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out) {
     return e == hipSuccess ? 0 : BVG_E_HIP;
 }
 
+// Per-handle device workspace for the materialising calls: grown on demand, kept between calls (a NodeIterator asks for batch
+// after batch of the same size; a fresh hipMalloc / hipFree pair per buffer and call cost more than the decode of a small batch).
+static int dr_ensure(bvg_graph* g, size_t bytes) {
+    if (bytes <= g->dr_ws_bytes) return 0;
+    if (g->dr_ws) { (void)hipFree(g->dr_ws); g->dr_ws = nullptr; g->dr_ws_bytes = 0; }
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(&g->dr_ws, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&g->dr_ws, bytes) != hipSuccess) { (void)hipGetLastError(); g->dr_ws = nullptr; return BVG_E_NOMEM; }
+        g->dr_ws_bytes = bytes; return 0;
+    }
+    g->dr_ws_bytes = want;
+    return 0;
+}
+
 static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t cap, uint64_t* n_succ, bool dev) {
     if (!g) return BVG_E_ARG;
     Shared* sh = g->sh;
@@ -921,37 +938,42 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
     if (from == to) { if (n_succ) *n_succ = 0; return 0; }
     HIPCHK(hipSetDevice(sh->device));
     const int64_t cnt = to - from;
-    int32_t* d_deg = nullptr; uint64_t* d_cum = nullptr; uint64_t* d_tmp = nullptr; int64_t* d_succ = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        if (d_deg && !(dev && outdeg)) (void)hipFree(d_deg);
-        if (d_cum) (void)hipFree(d_cum);
-        if (d_tmp) (void)hipFree(d_tmp);
-        if (d_succ && !dev) (void)hipFree(d_succ);
-    };
-#define DR_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP; } } while (0)
-    if (dev && outdeg) d_deg = outdeg; else DR_CHK(hipMalloc(&d_deg, (size_t)cnt * sizeof(int32_t)));
-    DR_CHK(hipMalloc(&d_cum, ((size_t)cnt + 1) * sizeof(uint64_t)));
-    DR_CHK(hipMalloc(&d_tmp, scan_tmp_elems(cnt) * sizeof(uint64_t)));
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // workspace: [cum | scan tmp | deg (unless the caller's device buffer takes them)] and, for host callers, the successors behind them
+    const size_t o_cum = 0, o_tmp = o_cum + al(((size_t)cnt + 1) * sizeof(uint64_t)), o_deg = o_tmp + al(scan_tmp_elems(cnt) * sizeof(uint64_t));
+    const size_t o_succ = o_deg + al((size_t)cnt * sizeof(int32_t));
+    int rc = dr_ensure(g, o_succ); if (rc) return rc;
+    auto at = [&](size_t off) { return (char*)g->dr_ws + off; };
+    int32_t* d_deg = (dev && outdeg) ? outdeg : (int32_t*)at(o_deg);
+    uint64_t* d_cum = (uint64_t*)at(o_cum);
     launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
-    launch_exclusive_scan(d_deg, d_cum, cnt, d_tmp, g->stream);
+    launch_exclusive_scan(d_deg, d_cum, cnt, (uint64_t*)at(o_tmp), g->stream);
     uint64_t total = 0;
-    DR_CHK(hipMemcpyAsync(&total, d_cum + cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
-    DR_CHK(hipStreamSynchronize(g->stream));
+    HIPCHK(hipMemcpyAsync(&total, d_cum + cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
     if (n_succ) *n_succ = total;
     if (total > cap || (!succ && total > 0)) {          // query / too small: report the size (and the outdegrees)
-        if (outdeg && !dev) DR_CHK(hipMemcpy(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
-        cleanup();
+        if (outdeg && !dev) HIPCHK(hipMemcpy(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
         return BVG_E_CAPACITY;
     }
-    if (dev) d_succ = succ; else DR_CHK(hipMalloc(&d_succ, (size_t)(total ? total : 1) * sizeof(int64_t)));
+    int64_t* d_succ = succ;
+    if (!dev) {
+        if (o_succ + (size_t)(total ? total : 1) * sizeof(int64_t) > g->dr_ws_bytes) {
+            // growing moves the workspace: the prefix sums are recomputed rather than copied (two tiny kernels)
+            rc = dr_ensure(g, o_succ + (size_t)(total ? total : 1) * sizeof(int64_t)); if (rc) return rc;
+            d_deg = (int32_t*)at(o_deg); d_cum = (uint64_t*)at(o_cum);
+            launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
+            launch_exclusive_scan(d_deg, d_cum, cnt, (uint64_t*)at(o_tmp), g->stream);
+        }
+        d_succ = (int64_t*)at(o_succ);
+    }
     rc = run_decode(g, from, to, true, d_cum, d_succ, d_deg, nullptr);
     if (rc == 0 && !dev) {
-        if (total) DR_CHK(hipMemcpy(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (outdeg) DR_CHK(hipMemcpy(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost));
+        // device -> host on the handle's stream: at PCIe rate when the caller's buffers are page-locked (bvg_host_alloc)
+        if (total) HIPCHK(hipMemcpyAsync(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+        if (outdeg) HIPCHK(hipMemcpyAsync(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
     }
-    cleanup();
-#undef DR_CHK
     return rc;
 }
 
@@ -962,6 +984,13 @@ int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg,
     return decode_range_impl(g, from, to, (int32_t*)d_outdeg, (int64_t*)d_succ, succ_cap, n_succ, true);
 }
 
+void* bvg_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void bvg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
     if (!g || (!nodes && count) || count < 0) return BVG_E_ARG;
     Shared* sh = g->sh;
@@ -970,36 +999,40 @@ int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int3
     if (count == 0) return 0;
     if (count > 0x3FFFFFFF) return BVG_E_ARG;
     HIPCHK(hipSetDevice(sh->device));
-    int64_t* d_nodes = nullptr; int32_t* d_deg = nullptr; uint64_t *d_first = nullptr, *d_cum = nullptr, *d_tmp = nullptr, *d_mask = nullptr;
-    uint32_t* d_halo = nullptr; int64_t* d_succ = nullptr;
-    auto cleanup = [&]() { for (void* p : {(void*)d_nodes, (void*)d_deg, (void*)d_first, (void*)d_cum, (void*)d_tmp, (void*)d_mask, (void*)d_halo, (void*)d_succ}) if (p) (void)hipFree(p); };
-#define SB_CHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP; } } while (0)
-    SB_CHK(hipMalloc(&d_nodes, (size_t)count * sizeof(int64_t)));
-    SB_CHK(hipMalloc(&d_deg, (size_t)count * sizeof(int32_t)));
-    SB_CHK(hipMalloc(&d_first, (2 * (size_t)count + 1) * sizeof(uint64_t)));
-    SB_CHK(hipMalloc(&d_cum, ((size_t)count + 1) * sizeof(uint64_t)));
-    SB_CHK(hipMalloc(&d_tmp, scan_tmp_elems(count) * sizeof(uint64_t)));
-    SB_CHK(hipMalloc(&d_halo, 2 * (size_t)count * sizeof(uint32_t)));
-    SB_CHK(hipMalloc(&d_mask, 2 * (size_t)count * sizeof(uint64_t)));
-    SB_CHK(hipMemcpyAsync(d_nodes, nodes, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
-    launch_outdegrees_gather(sh->d_graph, sh->nbytes, sh->d_offsets, d_nodes, count, sh->p.outdegree_coding, d_deg, d_first, g->stream);
-    launch_exclusive_scan(d_deg, d_cum, count, d_tmp, g->stream);
-    launch_plan_halo(sh->d_graph, sh->nbytes, sh->d_offsets, sh->p.nodes, d_first, (uint32_t)(2 * count), sh->p.window_size, codings_of(sh->p), d_halo, d_mask, g->stream);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t c = (size_t)count;
+    const size_t o_nodes = 0, o_deg = o_nodes + al(c * sizeof(int64_t)), o_first = o_deg + al(c * sizeof(int32_t)), o_cum = o_first + al((2 * c + 1) * sizeof(uint64_t));
+    const size_t o_tmp = o_cum + al((c + 1) * sizeof(uint64_t)), o_halo = o_tmp + al(scan_tmp_elems(count) * sizeof(uint64_t)), o_mask = o_halo + al(2 * c * sizeof(uint32_t));
+    const size_t o_succ = o_mask + al(2 * c * sizeof(uint64_t));
+    int rc = dr_ensure(g, o_succ); if (rc) return rc;
+    auto at = [&](size_t off) { return (char*)g->dr_ws + off; };
+    auto prepare = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(at(o_nodes), nodes, c * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
+        launch_outdegrees_gather(sh->d_graph, sh->nbytes, sh->d_offsets, (const int64_t*)at(o_nodes), count, sh->p.outdegree_coding, (int32_t*)at(o_deg), (uint64_t*)at(o_first), g->stream);
+        launch_exclusive_scan((const int32_t*)at(o_deg), (uint64_t*)at(o_cum), count, (uint64_t*)at(o_tmp), g->stream);
+        launch_plan_halo(sh->d_graph, sh->nbytes, sh->d_offsets, sh->p.nodes, (const uint64_t*)at(o_first), (uint32_t)(2 * count), sh->p.window_size, codings_of(sh->p), (uint32_t*)at(o_halo), (uint64_t*)at(o_mask), g->stream);
+        return 0;
+    };
+    rc = prepare(); if (rc) return rc;
     uint64_t total = 0;
-    std::vector<uint32_t> halo(2 * (size_t)count);
-    SB_CHK(hipMemcpyAsync(&total, d_cum + count, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
-    SB_CHK(hipMemcpyAsync(halo.data(), d_halo, halo.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
-    SB_CHK(hipStreamSynchronize(g->stream));
+    std::vector<uint32_t> halo(2 * c);
+    HIPCHK(hipMemcpyAsync(&total, (uint64_t*)at(o_cum) + count, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(halo.data(), at(o_halo), halo.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
     if (n_succ) *n_succ = total;
-    if (outdeg) SB_CHK(hipMemcpy(outdeg, d_deg, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (total > succ_cap || (!succ && total > 0)) { cleanup(); return BVG_E_CAPACITY; }
-    for (int64_t i = 0; i < count; i++) if (halo[2 * (size_t)i] == 0xFFFFFFFFu) { cleanup(); return BVG_E_UNSUPPORTED; }   // reference chain > 64 nodes back
-    SB_CHK(hipMalloc(&d_succ, (size_t)(total ? total : 1) * sizeof(int64_t)));
-    BatchPlan bp{d_first, d_halo, d_mask, (uint32_t)count};
-    int rc = run_decode(g, 0, sh->p.nodes, true, d_cum, d_succ, nullptr, nullptr, &bp);
-    if (rc == 0 && total) SB_CHK(hipMemcpy(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost));
-    cleanup();
-#undef SB_CHK
+    if (outdeg) HIPCHK(hipMemcpy(outdeg, at(o_deg), c * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (total > succ_cap || (!succ && total > 0)) return BVG_E_CAPACITY;
+    for (int64_t i = 0; i < count; i++) if (halo[2 * (size_t)i] == 0xFFFFFFFFu) return BVG_E_UNSUPPORTED;   // reference chain > 64 nodes back
+    if (o_succ + (size_t)(total ? total : 1) * sizeof(int64_t) > g->dr_ws_bytes) {
+        rc = dr_ensure(g, o_succ + (size_t)(total ? total : 1) * sizeof(int64_t)); if (rc) return rc;
+        rc = prepare(); if (rc) return rc;                                   // the workspace moved: redo the (cheap) preparation in the new one
+    }
+    BatchPlan bp{(const uint64_t*)at(o_first), (const uint32_t*)at(o_halo), (const uint64_t*)at(o_mask), (uint32_t)count};
+    rc = run_decode(g, 0, sh->p.nodes, true, (const uint64_t*)at(o_cum), (int64_t*)at(o_succ), nullptr, nullptr, &bp);
+    if (rc == 0 && total) {
+        HIPCHK(hipMemcpyAsync(succ, at(o_succ), (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+    }
     return rc;
 }
 
