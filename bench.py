@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--base-nodes", type=int, default=1 << 21, help="nodes of the generated base graph")
     ap.add_argument("--target-gib", type=float, default=0.0, help="size of the tiled .graph stream per GPU (0 = the shape's default: 512 tiles for eu15, 8 GiB otherwise)")
     ap.add_argument("--shape", default="eu15", choices=sorted(SHAPES))
+    ap.add_argument("--tiles", type=int, default=0, help="explicit number of tiles of the base graph (overrides --target-gib)")
+    ap.add_argument("--allow-wide", action="store_true", help="let the tiled graph pass 2^31 nodes: the 64-bit successor kernels run (dtype u64)")
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N > 1: strong = shards of ONE graph (default), weak = one graph per rank")
     ap.add_argument("--balance", default="arcs", choices=["arcs", "bits", "nodes"])
     ap.add_argument("--block-bits", type=int, default=0)
@@ -102,7 +104,10 @@ def main():
         copies = max(1, int((args.target_gib or 8.0) * (1 << 30) / max(base_bytes, 1)))
     else:
         copies = tiles_default * (1 << 21) // args.base_nodes if args.base_nodes <= (1 << 21) else tiles_default
-    copies = max(1, min(copies, ((1 << 31) - 1) // args.base_nodes))    # stay on the 32-bit successor kernels
+    if args.tiles:
+        copies = args.tiles
+    if not args.allow_wide:
+        copies = max(1, min(copies, ((1 << 31) - 1) // args.base_nodes))    # stay on the 32-bit successor kernels
     free0 = torch.cuda.mem_get_info(dev)[0]
     t0 = time.time()
     base = W.BVGraph.from_memory(st.params, st.graph, st.offsets, device=dev)
@@ -150,7 +155,8 @@ def main():
         n0 = st.params.nodes
         nb = rank * n_graph if scaling == "weak" else 0
         j_lo, j_hi = (lo + n0 - 1) // n0, hi // n0                       # whole tiles inside [lo, hi)
-        for j in sorted({j_lo, (j_lo + j_hi) // 2, j_hi - 1}) if j_hi > j_lo else []:
+        jb = (1 << 31) // n0                                            # the tiles on either side of node 2^31 (64-bit successor values)
+        for j in sorted({j_lo, (j_lo + j_hi) // 2, j_hi - 1} | ({jb - 1, jb} & set(range(j_lo, j_hi)))) if j_hi > j_lo else []:
             ro = og.scan(0, n0, node_base=nb + j * n0, threads=threads)
             rg = g.scan(j * n0, (j + 1) * n0)
             assert (rg["arcs"], rg["chk"]) == (ro["arcs"], ro["chk"]), "GPU scan of tile %d disagrees with the CPU oracle" % j
@@ -196,7 +202,7 @@ def main():
                                    + "; RCCL all-reduce of {arcs,chk} only"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
-                         "kernel": "bvg::rows_kernel<u32,scan,tasks> (tier 0) with rows_wg_kernel<u32,4> (big-LDS classes), decode_kernel<slow> (giants) and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream", "kernel_ms": k_ms,
+                         "kernel": "bvg::rows_kernel<%s,scan,tasks> (tier 0) with rows_wg_kernel<u32,4> (big-LDS classes), decode_kernel<slow> (giants) and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream" % ("u32" if n_graph < (1 << 31) else "u64"), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": gbytes, "index_bytes_per_launch": r["index_bytes"]},
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
             "index_build_s": max(first_scan_s - steady_s, 0.0), "hbm_resident_bytes": int(resident),

@@ -22,6 +22,7 @@
 // kernel instantiated over a global-memory pool (the slow path).
 #include "bvg_kernels.h"
 
+#include <algorithm>
 #include <type_traits>
 
 namespace bvg {
@@ -486,8 +487,8 @@ __device__ __forceinline__ uint64_t load_bits64(const uint8_t* src, uint64_t bit
     return w;
 }
 __global__ void tile_graph_kernel(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_words, uint64_t total_bits) {
-    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= dst_words) return;
+    // grid-stride: a launch may not exceed 2^32 threads (a 47 GB stream has 5.9e9 words)
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < dst_words; w += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t P = w * 64, val = 0;
     if (P < total_bits) {
         uint64_t off = P % src_bits, rem = src_bits - off;
@@ -506,14 +507,15 @@ __global__ void tile_graph_kernel(const uint8_t* src, uint64_t src_bits, uint8_t
         if (total_bits - P < 64) val &= ~(~0ull >> (total_bits - P));
     }
     reinterpret_cast<uint64_t*>(dst)[w] = __builtin_bswap64(val);
+    }
 }
 __global__ void tile_offsets_kernel(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t tot = n * copies;
-    if (i > tot) return;
-    if (i == tot) { dst[i] = (uint64_t)copies * src_bits; return; }
-    int64_t c = i / n, r = i - c * n;
-    dst[i] = (uint64_t)c * src_bits + src[r];
+    const int64_t tot = n * copies;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= tot; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i == tot) { dst[i] = (uint64_t)copies * src_bits; continue; }
+        int64_t c = i / n, r = i - c * n;
+        dst[i] = (uint64_t)c * src_bits + src[r];
+    }
 }
 
 }  // namespace
@@ -612,11 +614,11 @@ void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t*
 
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s) {
     uint64_t words = dst_bytes / 8;
-    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, src, src_bits, dst, words, src_bits * (uint64_t)copies);
+    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)std::min<uint64_t>((words + 255) / 256, 1u << 22)), dim3(256), 0, s, src, src_bits, dst, words, src_bits * (uint64_t)copies);
 }
 void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s) {
     int64_t tot = n * copies + 1;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, n, src_bits, dst, copies);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 1 << 22)), dim3(256), 0, s, src, n, src_bits, dst, copies);
 }
 
 }  // namespace bvg
