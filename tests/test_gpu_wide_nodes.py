@@ -10,15 +10,14 @@ pytestmark = pytest.mark.gpu
 
 
 def test_scan_and_decode_past_2_to_31_nodes(W, tools, oracle):
-    import torch
-    free = torch.cuda.mem_get_info(0)[0]
-    if free < 40 << 30:
-        pytest.skip("needs ~25 GB of HBM for the offsets of 2^31 nodes")
     n0 = 1 << 19
     st = tools.synth_store(n0, seed=77, synth=tools.web_like(mean_deg=3.0, p_empty=0.5, max_deg=200), threads=4)
     tiles = (1 << 31) // n0 + 3
     base = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
-    g = base.tile(tiles)
+    try:
+        g = base.tile(tiles)                                  # ~18 GB of offsets for 2^31 nodes
+    except MemoryError:
+        pytest.skip("needs ~25 GB of HBM")
     n = g.num_nodes()
     assert n > (1 << 31) and g.num_arcs() == st.stats["arcs"] * tiles
     og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)

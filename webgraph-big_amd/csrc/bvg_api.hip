@@ -111,7 +111,7 @@ struct bvg_graph {
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     struct Pred {
         uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
-        std::vector<uint8_t> learned; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
+        std::vector<uint8_t> learned; uint64_t learned_version = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
     } pred;
 };
 
@@ -474,23 +474,31 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 pool = std::max<uint64_t>(pool, 1024);
             } else if (task) {
                 // resident waves per CU step down with the LDS footprint: take every byte of the step the pool lands on
-                const uint64_t lds_cu = 160 * 1024, fixed = (uint64_t)a.lds_stage_words * 4 + 1536 + 256;   // window + static arrays (+ slack)
-                auto foot = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed + 1023) & ~1023ull; };
+                const uint64_t lds_cu = 160 * 1024, fixed = 1536 + 64;   // static arrays (+ slack); the task variant keeps the stream window INSIDE the pool
+                auto foot = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed + 127) & ~127ull; };
                 uint64_t waves = std::max<uint64_t>(1, lds_cu / foot(pool));
                 // Two wavefronts per SIMD (8 per CU) is the step that pays on dense graphs: below it the CU's SIMDs sit idle behind
                 // LDS latency, and a row that shrinks to ~40 lists costs less than the lost wavefronts (eu15 shape, 4 GiB: 90.0 G
                 // edges/s at 6 per CU with 54 lists per row, 98.7 G at 8 per CU with 43; profiles/r02/occ_sweep15.sh).
-                if (waves < 8 && !getenv("BVG_STAGE")) {
-                    uint64_t p8 = pool;
-                    const uint32_t st8 = std::min<uint32_t>(a.lds_stage_words, 512);
-                    const uint64_t fixed8 = (uint64_t)st8 * 4 + 1536 + 256;
-                    auto foot8 = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed8 + 1023) & ~1023ull; };
-                    while (p8 > 1024 && lds_cu / foot8(p8) < 8) p8 -= 64;
-                    if ((double)p8 >= 40.0 * avg && lds_cu / foot8(p8) >= 8) { pool = p8; a.lds_stage_words = st8; waves = lds_cu / foot8(p8); }
+                // Resident wavefronts per CU are what this kernel's throughput follows (linear from 1 to 8, profiles/r02/ldspad.sh), as
+                // long as a row still holds enough lists to fill its lock-step passes: take the largest EVEN count (odd ones load
+                // the four SIMDs unevenly: 9 and 11 measured below 8 and 10) whose pool holds ~48 average lists; dense graphs end at
+                // 8-10, sparse ones at the 16 the registers allow (profiles/r02: eu 10 per CU 118.8 G edges/s vs 8: 117.3, 9: 113.8;
+                // eu15 8: 121.6, 9: 111.0, 10: 111.3).
+                if (!getenv("BVG_STAGE")) {
+                    for (uint64_t w : {16ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
+                        uint64_t pw = wide ? 4096 : 8192;
+                        while (pw > 1024 && lds_cu / foot(pw) < w) pw -= 32;
+                        if (lds_cu / foot(pw) >= w && ((double)pw >= 48.0 * avg || w == 4)) { pool = pw; waves = lds_cu / foot(pw); a.lds_stage_words = std::min<uint32_t>(a.lds_stage_words, 512); break; }
+                    }
                 }
-                const uint64_t fixed2 = (uint64_t)a.lds_stage_words * 4 + 1536 + 256;
-                auto foot2 = [&](uint64_t pe) { return ((pe + std::max<uint64_t>(256, pe / 8)) * esz + fixed2 + 1023) & ~1023ull; };
-                while (pool + 64 <= (wide ? 4096u : 8192u) && lds_cu / foot2(pool + 64) == waves) pool += 64;
+                if (getenv("BVG_WAVES")) {                                 // experiments: aim at this many resident wavefronts per CU
+                    const uint64_t w = std::max<uint64_t>(1, strtoull(getenv("BVG_WAVES"), nullptr, 10));
+                    uint64_t pw = wide ? 4096 : 8192;
+                    while (pw > 1024 && lds_cu / foot(pw) < w) pw -= 64;
+                    pool = pw; waves = lds_cu / foot(pw);
+                }
+                while (pool + 32 <= (wide ? 4096u : 8192u) && lds_cu / foot(pool + 32) == waves) pool += 32;
             }
             if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
@@ -509,7 +517,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const uint32_t pool0 = a.lds_pool_elems;
             const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u);
             const bool rekey = pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
-            if (rekey) { pd.learned.assign(nblocks, 0); pd.dirty = false; }
+            // what the cascade taught about a block is kept per block of the PLAN, so a scan of another node range (a shard, an
+            // iterator batch, the bench's verification of single tiles) does not throw it away
+            if (pd.learned.size() != pl.nblk || pd.learned_version != pl.version || pd.learned_pool0 != pool0 || pd.learned_mode != pmode) {
+                pd.learned.assign(pl.nblk, 0); pd.learned_version = pl.version; pd.learned_pool0 = pool0; pd.learned_mode = pmode;
+            }
+            if (rekey) pd.dirty = false;
             if (rekey || pd.dirty) {
                 std::vector<uint32_t> L[6];
                 uint64_t gneed = 0;
@@ -521,7 +534,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     if (long_record) c = 5;
                     else if (need <= pool0) c = 0;
                     else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
-                    if (pd.learned[i] > c) { c = pd.learned[i]; if (c == 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
+                    if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c == 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
                     if (c == 5 && need > gneed) gneed = need;
                     L[c].push_back(lo + i);
                 }
@@ -629,11 +642,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 bvg_graph::Pred& pd = g->pred;
                 std::sort(again.begin(), again.end());
                 for (uint32_t id : work)
-                    if (id >= lo && id - lo < pd.learned.size() && !std::binary_search(again.begin(), again.end(), id)) { pd.learned[id - lo] = (uint8_t)(c + 1); pd.dirty = true; }
+                    if (id < pd.learned.size() && !std::binary_search(again.begin(), again.end(), id)) { pd.learned[id] = (uint8_t)(c + 1); pd.dirty = true; }
             }
         }
         work.swap(rest);
-        if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id >= lo && id - lo < pd.learned.size()) { pd.learned[id - lo] = 5; pd.dirty = true; } }
+        if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 5; pd.dirty = true; } }
     }
     // ---- tier 2: global-memory pools (kept in the handle), grown until every remaining block fits
     uint64_t pool_elems = 1ull << 20;

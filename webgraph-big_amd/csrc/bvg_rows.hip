@@ -60,8 +60,17 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
 
     T* const pool = reinterpret_cast<T*>(dyn_lds);
     T* const scr = pool + a.lds_pool_elems;
-    const uint32_t* const stage = reinterpret_cast<const uint32_t*>(scr + a.lds_scr_elems);
-    uint32_t* const stage_w = const_cast<uint32_t*>(stage);
+    // The stream window is only read while a row is PARSED (outdegrees, headers, residual gaps); the row's lists are only written
+    // while it is EMITTED.  The task variant therefore lays the window over the part of the pool the row's lists will take
+    // (right behind the lists of the previous W nodes; the residuals of the row are parked at the far end): 2-4 KiB of LDS less
+    // per wavefront, i.e. one more resident wavefront per CU -- and throughput is linear in those (profiles/r02/ldspad.sh).
+    constexpr bool OVL = TASK;
+    constexpr uint32_t kAl = 16 / sizeof(T);                                 // elements per 16 bytes (the window is filled with 16-byte stores)
+    const uint32_t SWE = OVL ? (uint32_t)((a.lds_stage_words * 4u + sizeof(T) - 1) / sizeof(T)) : 0u;   // window size in pool elements
+    const uint32_t* stage = reinterpret_cast<const uint32_t*>(scr + a.lds_scr_elems);
+    uint32_t* stage_w = const_cast<uint32_t*>(stage);
+    uint32_t stage_off = 0;                                                  // OVL: first pool element of the window
+    bool ovl_dirty = false;                                                  // OVL: a list of the last row reached into the window
     const uint32_t CAP = a.lds_pool_elems, SCR = a.lds_scr_elems;
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
@@ -112,6 +121,30 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
         const uint32_t left = (uint32_t)(e - r0 > 64 ? 64 : e - r0);
+        auto compact = [&]() {
+            // keep only the lists of the last W nodes, moved to the front of the pool
+            uint32_t my_d = 0, my_base = 0; const int64_t y = r0 - (int64_t)W + (int64_t)lane;
+            const bool livelane = lane < W && y >= hs;
+            if (livelane) { my_d = nd_d[(uint32_t)y & RM]; my_base = nd_base[(uint32_t)y & RM]; }
+            const uint32_t nincl = wave_incl_scan32(my_d);
+            const uint32_t nbase = nincl - my_d;
+            for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
+                const uint32_t src = lane_get(my_base, jn), dst = lane_get(nbase, jn), len = lane_get(my_d, jn);
+                if (src != dst)
+                    for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
+            }
+            if (livelane) nd_base[(uint32_t)y & RM] = nbase;
+            pool_used = lane_get(nincl, 63);
+            __syncthreads();
+        };
+        if (OVL) {
+            if (pool_used > 0) compact();                                     // every row starts from the window lists alone
+            const uint32_t noff = (pool_used + kAl - 1) & ~(kAl - 1);
+            if (noff + SWE > CAP) { failed = true; fail_need = pool_used + SWE + (pool_used >> 2) + 64; break; }   // the window lists leave no room
+            if (noff != stage_off || ovl_dirty) stg_bits = 0;                 // the previous row's lists were written over the window
+            stage_off = noff; ovl_dirty = false;
+            stage_w = reinterpret_cast<uint32_t*>(pool + stage_off); stage = stage_w;
+        }
         {   // (re)stage the window when this row's records are not covered by it
             const uint64_t row_lo = lane_get64(off_x, 0);
             const uint64_t row_hi = lane_get64(rec_end, left - 1);
@@ -153,23 +186,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const uint32_t incl = wave_incl_scan32(dclamp);
         uint32_t avail = CAP - pool_used;
         const uint32_t total = lane_get(incl, 63);
-        if (total > avail && pool_used > 0) {
-            // compact: keep only the lists of the last W nodes, moved to the front of the pool
-            uint32_t my_d = 0, my_base = 0; const int64_t y = r0 - (int64_t)W + (int64_t)lane;
-            const bool livelane = lane < W && y >= hs;
-            if (livelane) { my_d = nd_d[(uint32_t)y & RM]; my_base = nd_base[(uint32_t)y & RM]; }
-            const uint32_t nincl = wave_incl_scan32(my_d);
-            const uint32_t nbase = nincl - my_d;
-            for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
-                const uint32_t src = lane_get(my_base, jn), dst = lane_get(nbase, jn), len = lane_get(my_d, jn);
-                if (src != dst)
-                    for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
-            }
-            if (livelane) nd_base[(uint32_t)y & RM] = nbase;
-            pool_used = lane_get(nincl, 63);
-            avail = CAP - pool_used;
-            __syncthreads();
-        }
+        if (!OVL && total > avail && pool_used > 0) { compact(); avail = CAP - pool_used; }
         // Scan mode stores a merged list only if a later node can copy from it (LEAN): the row is first sized
         // optimistically on the outdegrees and cut to what really fits once the references are known.
         uint32_t k = kwin;
@@ -284,6 +301,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 const uint32_t rincl = wave_incl_scan32(rsz);
                 rtb = CAP - (rincl > CAP ? CAP : rincl);
                 tot = sincl + rincl;
+                if (OVL && rincl + stage_off + SWE > CAP) tot = 0xFFFFFFFFu;     // the parked residuals may not reach down into the window
             } else {
                 size = (needed && lane < k) ? (stored ? dclamp : (nres > CAP ? CAP + 1 : nres)) : 0u;
                 sincl = wave_incl_scan32(size);
@@ -299,7 +317,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             {
                 uint32_t d0 = lane_get(d, 0); const uint32_t n0 = lane_get(nres, 0);
                 if (TASK && d0 <= 0x3FFFFFFFu) d0 += (n0 > d0 ? d0 : n0) + 1u;
-                fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64;
+                fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64 + SWE;
             }
             break;
         }
@@ -307,6 +325,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const uint32_t base = pool_used + (sincl - size);
         if (act) nd_base[(uint32_t)x & RM] = base;
         pool_used += lane_get(sincl, k - 1);
+        if (OVL && pool_used > stage_off) ovl_dirty = true;
         // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
         uint64_t nxt_off = 0, nxt_end = 0;
         {
@@ -857,7 +876,8 @@ void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     dim3 grid(nblocks), block(64);
     const bool gen = !(a.cod.outdegree == BVG_GAMMA && a.cod.reference == BVG_UNARY && a.cod.block_count == BVG_GAMMA &&
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
-    size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (size_t)a.lds_stage_words * 4;
+    const bool task0 = a.emit_tasks != 0;
+    size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (task0 ? 0 : (size_t)a.lds_stage_words * 4);   // (task variant: the window lies inside the pool)
     if (getenv("BVG_LDSPAD")) dyn += (size_t)atoi(getenv("BVG_LDSPAD"));   // occupancy experiments: unused LDS behind the window
     const bool task = a.emit_tasks != 0;
 #define BVG_RL(T, M) do { if (task) { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, true>), grid, block, dyn, s, a); \
