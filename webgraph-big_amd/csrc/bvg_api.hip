@@ -17,6 +17,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -374,6 +375,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.node_base = g->node_base; a.acc = g->d_acc; a.acc_mask = getenv("BVG_NOSTRIPE") ? 0u : kAccStripes - 1; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
     a.dbg = getenv("BVG_DBG") ? (uint32_t)strtoul(getenv("BVG_DBG"), nullptr, 10) : 0;
+#ifndef BVG_PROF
+    a.dbg &= (16u | 32u | 64u);                             // forcing an emission form and the work counters leave the results alone; the
+                                                            // phase-skipping bits (1, 2, 4, 128) exist in the profiling build only
+#endif
     // Row-kernel variant: splitting lists into tasks pays on dense or reference-free graphs; sparse graphs with reference
     // chains (several short levels per row) are served better by the pipelined node-per-lane loop alone.
     {
@@ -386,8 +391,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (!batch && rows_default && pl.skip_total && pl.skip_wide == wide && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state.load(std::memory_order_acquire))) {
         a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val;
     }
+#ifdef BVG_EXPERIMENTAL
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
     const bool legacy = (g->tun.reserved & 0xFF) == 1;     // A/B switch: the generic row kernel (BitCursor) in LDS as tier 0/1
+#else
+    const bool stream = false, legacy = false;             // (`make experimental` builds the streaming kernel and the generic LDS kernel as tier 0)
+#endif
     a.grab_threshold = (g->tun.reserved >> 8) ? (g->tun.reserved >> 8) : 40;
     const size_t esz = wide ? 8 : 4;
     const double avg = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
@@ -397,7 +406,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         while (words < 1024 && (double)words * 32.0 < bits_per_node * 64.0 * 1.5) words *= 2;
         a.lds_stage_words = words;
     }
-    if (getenv("BVG_STAGE")) a.lds_stage_words = (uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u;
+    if (getenv("BVG_STAGE")) a.lds_stage_words = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u, 64u), 4096u);
 
     // Workgroup variant of the row kernel (several wavefronts share one pool): scan mode, default codings, 32-bit successors
     int wg_nw = 0;
@@ -500,7 +509,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 }
                 while (pool + 32 <= (wide ? 4096u : 8192u) && lds_cu / foot(pool + 32) == waves) pool += 32;
             }
-            if (getenv("BVG_POOL")) pool = strtoull(getenv("BVG_POOL"), nullptr, 10);
+            if (getenv("BVG_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(getenv("BVG_POOL"), nullptr, 10), 256), wide ? 6144 : 12288);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
         }
         if (batch) {                                        // one block per request: the even entries of the per-call plan
@@ -553,7 +562,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0;
             if (pd.count[5]) {
                 gpool_elems = 1ull << 16; while (gpool_elems < pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(pd.count[5], getenv("BVG_GBATCH") ? (uint32_t)atoi(getenv("BVG_GBATCH")) : 1024u);
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(pd.count[5], getenv("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(getenv("BVG_GBATCH"))) : 1024u);
                 const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
                 if (bytes > g->giant_ws_bytes) {
                     if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
@@ -602,9 +611,13 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             } else { r = fetch_failures(work); if (r) return r; }
             slow_blocks += (uint32_t)work.size();                              // blocks the prediction missed: re-run by the cascade below
         } else {
+#ifdef BVG_EXPERIMENTAL
         r = timed("tier0 (LDS)", nblocks, [&] { if (stream) launch_stream_decode(a, nblocks, wide, materialise, g->stream);
                                               else if (legacy) launch_decode(a, nblocks, wide, materialise, false, g->stream);
                                               else launch_rows_any(a, nblocks, g->stream); });
+#else
+        r = timed("tier0 (LDS)", nblocks, [&] { launch_rows_any(a, nblocks, g->stream); });
+#endif
         if (r) return r;
         launches++;
         r = fetch_failures(work); if (r) return r;
@@ -753,6 +766,15 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
 }  // namespace
 
 // ================================================================================================
+// No C++ exception may cross the C ABI (a JVM behind JNI would be torn down by std::terminate): entry points that allocate
+// host memory run inside this guard.
+template <typename F> static int guarded(F&& f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return BVG_E_NOMEM; }
+    catch (const std::length_error&) { return BVG_E_ARG; }
+    catch (...) { return BVG_E_STATE; }
+}
+
 extern "C" {
 
 int bvg_abi_version(void) { return BVG_ABI_VERSION; }
@@ -849,12 +871,15 @@ int bvg_decode_offsets(const uint8_t* obytes, size_t nbytes, int64_t nodes, int 
 int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out) {
     if (!basename || !out) return BVG_E_ARG;
     if (load_mode < BVG_LOAD_OFFLINE || load_mode > BVG_LOAD_MAPPED) return BVG_E_ARG;
+    return guarded([&]() -> int {
     std::string base(basename);
     std::vector<uint8_t> props, graph, offs;
     int r = read_file(base + ".properties", props); if (r) return r;
     bvg_params p;
     r = bvg_parse_properties((const char*)props.data(), props.size(), &p); if (r) return r;
+    r = check_params(p); if (r) return r;                        // before anything is sized from the file's own numbers
     r = read_file(base + ".graph", graph); if (r) return r;
+    if ((uint64_t)p.nodes > (uint64_t)graph.size() * 8 + 1) return BVG_E_IO;   // every record takes at least one bit: a corrupt `nodes`
     // Standard / mapped loads read basename.offsets (BVG:1545-1558).  Sequential / offline loads (BVG:1345-1464) do not
     // have to have it: the index is then derived from the stream on the device.
     r = read_file(base + ".offsets", offs);
@@ -865,6 +890,7 @@ int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out) {
     std::vector<uint64_t> offsets((size_t)p.nodes + 1);
     r = bvg_decode_offsets(offs.data(), offs.size(), p.nodes, p.offset_coding, offsets.data()); if (r) return r;
     return open_common(&p, graph.data(), nullptr, graph.size(), offsets.data(), nullptr, device, out);
+    });
 }
 
 int bvg_open_mem(const bvg_params* p, const uint8_t* graph, uint64_t nbytes, const uint64_t* offsets, int device, bvg_graph** out) {
@@ -991,10 +1017,10 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
 }
 
 int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
-    return decode_range_impl(g, from, to, outdeg, succ, succ_cap, n_succ, false);
+    return guarded([&] { return decode_range_impl(g, from, to, outdeg, succ, succ_cap, n_succ, false); });
 }
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ) {
-    return decode_range_impl(g, from, to, (int32_t*)d_outdeg, (int64_t*)d_succ, succ_cap, n_succ, true);
+    return guarded([&] { return decode_range_impl(g, from, to, (int32_t*)d_outdeg, (int64_t*)d_succ, succ_cap, n_succ, true); });
 }
 
 void* bvg_host_alloc(size_t bytes) {
@@ -1004,7 +1030,7 @@ void* bvg_host_alloc(size_t bytes) {
 }
 void bvg_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
+static int bvg_successors_batch_impl(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
     if (!g || (!nodes && count) || count < 0) return BVG_E_ARG;
     Shared* sh = g->sh;
     for (int64_t i = 0; i < count; i++) if (nodes[i] < 0 || nodes[i] >= sh->p.nodes) return BVG_E_ARG;      // BVG:863
@@ -1049,7 +1075,7 @@ int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int3
     return rc;
 }
 
-int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) {
+static int bvg_scan_impl(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) {
     if (!g || !out) return BVG_E_ARG;
     Shared* sh = g->sh;
     if (from < 0 || to > sh->p.nodes || from > to) return BVG_E_ARG;
@@ -1192,7 +1218,7 @@ int bvg_transpose_dev(bvg_graph* g, void* d_toffsets, void* d_tsucc, uint64_t ts
 
 // Arc-balanced split points (the skipTo() walk over algo/EliasFanoCumulativeOutdegreeList.java:30-75 that
 // algo/HyperBall.java:748-768 uses for its tasks): bounds[j] = first node whose cumulative outdegree reaches j * arcs / k.
-int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) {
+static int bvg_split_by_arcs_impl(bvg_graph* g, int k, int64_t* bounds) {
     if (!g || !bounds || k < 1) return BVG_E_ARG;
     Shared* sh = g->sh;
     HIPCHK(hipSetDevice(sh->device));
@@ -1215,7 +1241,7 @@ int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) {
     return done(0);
 }
 
-int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) {
+static int bvg_split_by_bits_impl(bvg_graph* g, int k, int64_t* bounds) {
     if (!g || !bounds || k < 1) return BVG_E_ARG;
     Shared* sh = g->sh;
     HIPCHK(hipSetDevice(sh->device));
@@ -1250,7 +1276,7 @@ int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds) {
         if (balance == BVG_BALANCE_NODES) {
             const int64_t n = sh->p.nodes, m = n ? (n + k - 1) / k : 0;
             for (int i = 0; i <= k; i++) b[(size_t)i] = std::min<int64_t>((int64_t)i * m, n);
-        } else r = balance == BVG_BALANCE_BITS ? bvg_split_by_bits(g, k, b.data()) : bvg_split_by_arcs(g, k, b.data());
+        } else r = balance == BVG_BALANCE_BITS ? bvg_split_by_bits_impl(g, k, b.data()) : bvg_split_by_arcs_impl(g, k, b.data());
         if (r) return r;
         it = sh->shard_bounds.emplace(key, std::move(b)).first;
     }
@@ -1299,7 +1325,7 @@ int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_re
     return 0;
 }
 
-int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) {
+static int bvg_tile_impl(const bvg_graph* base, int64_t copies, bvg_graph** out) {
     if (!base || !out || copies < 1) return BVG_E_ARG;
     Shared* b = base->sh;
     HIPCHK(hipSetDevice(b->device));
@@ -1323,6 +1349,12 @@ int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) {
     (*out)->tun = base->tun;
     return 0;
 }
+
+int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) { return guarded([&] { return bvg_scan_impl(g, from, to, out); }); }
+int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) { return guarded([&] { return bvg_successors_batch_impl(g, nodes, count, outdeg, succ, succ_cap, n_succ); }); }
+int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) { return guarded([&] { return bvg_tile_impl(base, copies, out); }); }
+int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_arcs_impl(g, k, bounds); }); }
+int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_bits_impl(g, k, bounds); }); }
 
 uint64_t bvg_arc_mix(uint64_t x, uint64_t y) {
     uint64_t kx = splitmix64(x);

@@ -73,6 +73,7 @@ __device__ __forceinline__ uint32_t win32(const uint32_t* r, uint32_t rel) { ret
 __device__ __forceinline__ uint64_t win64(const uint32_t* r, uint32_t rel) { return bvg::win64<SWM>(r, rel); }
 __device__ __forceinline__ uint32_t decode_generic(const uint32_t* r, uint32_t rel, int coding, uint32_t k, uint64_t* out) { return decode_generic_w(bvg::win64<SWM>(r, rel), coding, k, out); }
 
+#ifdef BVG_EXPERIMENTAL   // the streaming data-flow kernel: parity-tested, slower than the row kernel; `make experimental`
 template <typename T, bool MAT, bool GEN>
 __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t sring[kStreamWords];
@@ -414,12 +415,14 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
     }
 }
 
+#endif  // BVG_EXPERIMENTAL
 // ---------------------------------------------------------------------------------------------------
 // Offsets index from a bare .graph: the records have to be walked one after the other (a record's
 // length is only known by parsing it: BVG:1003-1064), so ONE wavefront does it, all 64 lanes executing the
 // same parse in step over an LDS ring of the stream (every LDS read is a broadcast); the lanes are
 // used for the coalesced refills of the ring and for writing the offsets 64 at a time.
 constexpr uint32_t kDerWords = 2048, kDerMask = kDerWords - 1, kDerBits = kDerWords * 32;
+
 
 template <bool GEN>
 __global__ void __launch_bounds__(64) derive_offsets_kernel(const uint8_t* graph, uint64_t padded_bytes, uint64_t nbytes, int64_t n, int window,
@@ -522,6 +525,7 @@ void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t
     else hipLaunchKernelGGL((derive_offsets_kernel<false>), dim3(1), dim3(64), 0, s, graph, padded_bytes, nbytes, n, window, min_interval, cod, offsets, err);
 }
 
+#ifdef BVG_EXPERIMENTAL
 void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s) {
     if (nblocks == 0) return;
     dim3 grid(nblocks), block(64);
@@ -535,4 +539,5 @@ void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool
 #undef BVG_SL
 }
 
+#endif
 }  // namespace bvg
