@@ -109,6 +109,11 @@ void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t*
 void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod,
                            uint64_t* offsets, unsigned* err, hipStream_t s);
 
+// the same in parallel (bvg_derive.hip): chunks of the stream walked speculatively and iterated to the one consistent walk; 0 = done
+// (err[0] != 0 on a bad stream), < 0 = not applicable / did not settle: fall back to launch_derive_offsets
+int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod, uint64_t* offsets, unsigned* err,
+                            hipStream_t s, int* rounds);
+
 // synthetic tiling (bvg_tile)
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
 void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);
