@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../.."; R=$PWD
 tag=${1:-pmc}; shift
 args="${@:---shape eu --target-gib 2}"
-O=$R/gpurun_out/r02_$tag; rm -rf $O; mkdir -p $O
+O=$R/gpurun_out/r02_pmc_$tag; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" \
@@ -15,4 +15,4 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py $args --steps 2 --warmup 0 --no-cpu-baseline > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $O/p$i.log; }
 done
 cd $R
-python3 profiles/r02/pmc_summary.py $O | tee gpurun_out/r02_${tag}_summary.txt
+python3 profiles/r02/pmc_summary.py $O | tee gpurun_out/r02_pmc_${tag}_summary.txt

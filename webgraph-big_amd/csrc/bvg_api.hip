@@ -495,7 +495,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // 8-10, sparse ones at the 16 the registers allow (profiles/r02: eu 10 per CU 118.8 G edges/s vs 8: 117.3, 9: 113.8;
                 // eu15 8: 121.6, 9: 111.0, 10: 111.3).
                 if (!getenv("BVG_STAGE")) {
-                    for (uint64_t w : {16ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
+                    for (uint64_t w : {20ull, 16ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
                         uint64_t pw = wide ? 4096 : 8192;
                         while (pw > 1024 && lds_cu / foot(pw) < w) pw -= 32;
                         if (lds_cu / foot(pw) >= w && ((double)pw >= 48.0 * avg || w == 4)) { pool = pw; waves = lds_cu / foot(pw); a.lds_stage_words = std::min<uint32_t>(a.lds_stage_words, 512); break; }

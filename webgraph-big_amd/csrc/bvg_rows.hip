@@ -30,7 +30,7 @@
 #define BVG_ROWS_WAVES 6
 #endif
 #ifndef BVG_TASK_WAVES
-#define BVG_TASK_WAVES 4
+#define BVG_TASK_WAVES 5
 #endif
 
 namespace bvg {
@@ -359,7 +359,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             bool tbad = false;
             // RU tasks per lane and pass, decoded in one interleaved loop: a gap is a chain of dependent LDS reads and shifts
             // (~300 cycles), and with two wavefronts per SIMD nothing else hides it -- two independent chains per lane do.
-            constexpr uint32_t RU = kResUnroll, RP = 64u * RU;
+            auto task_passes = [&](auto RUc) {
+            constexpr uint32_t RU = decltype(RUc)::value, RP = 64u * RU;
             for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
                 {
                     const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
@@ -434,6 +435,10 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (tlast[u] && cnt[u] && trel[u] != tpend[u] && !tbad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
                 __syncthreads();
             }
+            };
+            // two chains per lane only when the row has the tasks to fill them: a half-empty second chain doubles the instructions of
+            // every step for nothing (reference-free graphs: 166 G edges/s with one chain, 136 G with two, profiles/r02)
+            if (kResUnroll >= 2 && Ttot > 96u) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
             if (((act && d == 0) || (parse && lane < k && nres == 0)) && rel != pend && !bad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
             bad |= tbad;
             if (ballot(tbad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
