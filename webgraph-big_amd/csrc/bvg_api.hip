@@ -106,6 +106,7 @@ struct bvg_graph {
     static constexpr int kSide = 5;            // [0] giants (global-memory kernel), [1..4] one per LDS size class
     hipStream_t side[kSide] = {}; hipEvent_t side_ev[kSide] = {};
     void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
+    void* flow_ws = nullptr; size_t flow_ws_bytes = 0; uint32_t flow_waves = 0;   // scratch of the flow scan kernel (bvg_flow.hip): one slice per resident wavefront
     void* dr_ws = nullptr; size_t dr_ws_bytes = 0;   // bvg_decode_range / bvg_successors_batch workspace, kept between calls (grown on demand)
     void* tr_ws = nullptr; size_t tr_ws_bytes = 0;   // bvg_transpose workspace, kept between calls
     size_t tr_o_cum = 0, tr_o_succ = 0;             // where the last transpose left the graph's own CSR in it (bvg_symmetrize)
@@ -426,7 +427,27 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_class = getenv("BVG_WGC") ? atoi(getenv("BVG_WGC")) : 4;   // measured on the 8 GiB eu shape: 258.6 ms (0), 254.9 (2), 254.6 (4)
         if (wg_class != 2 && wg_class != 4) wg_class = 0;
     }
+    // The flow scan kernel as tier 0 (bvg_flow.hip): full scans, default codings, 32-bit successors, windows up to 64.  Its LDS holds
+    // only the lists of the window that are really copied from, so it keeps more wavefronts resident than the row kernel.
+    bool flow = false; uint32_t flow_ring = 0;
+    {
+        const Codings& c = a.cod;
+        const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
+        if (getenv("BVG_FLOW") && atoi(getenv("BVG_FLOW")) && !materialise && !wide && !batch && dflt && g->skip_mode == 0 && rows_default && sh->p.window_size <= kMaxWindow) {
+            flow = true;
+            flow_ring = getenv("BVG_FLOW_RING") ? (uint32_t)std::min(8192, std::max(512, atoi(getenv("BVG_FLOW_RING")))) : 1536u;
+            const size_t per = flow_scratch_bytes_per_wave(sh->p.window_size);
+            const uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / (flow_lds_bytes(flow_ring) + 1536 + 64));
+            const uint32_t waves = 256u * std::max(1u, per_cu);
+            if (g->flow_waves != waves || g->flow_ws_bytes < per * waves) {
+                if (g->flow_ws) { (void)hipFree(g->flow_ws); g->flow_ws = nullptr; g->flow_ws_bytes = 0; }
+                if (hipMalloc(&g->flow_ws, per * waves) != hipSuccess) { (void)hipGetLastError(); flow = false; }
+                else { g->flow_ws_bytes = per * waves; g->flow_waves = waves; }
+            }
+        }
+    }
     auto launch_rows_any = [&](const DecodeArgs& aa, uint32_t nb, hipStream_t st, bool is_class = false) {
+        if (flow && !is_class && aa.work_list == g->pred.d_lists) { launch_flow_scan(aa, nb, g->flow_waves, g->flow_ws, flow_ring, st); return; }
         const int nw = is_class && wg_class ? wg_class : wg_nw;
         if (nw) launch_rows_wg_decode(aa, nb, nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
     };
@@ -524,7 +545,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
             bvg_graph::Pred& pd = g->pred;
             const uint32_t pool0 = a.lds_pool_elems;
-            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u);
+            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u);
+            const uint64_t cap0 = flow ? 6144 : pool0;                          // the flow kernel keeps long lists in its scratch area
             const bool rekey = pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
             // what the cascade taught about a block is kept per block of the PLAN, so a scan of another node range (a shard, an
             // iterator batch, the bench's verification of single tiles) does not throw it away
@@ -541,7 +563,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     const uint64_t need = md + md / 8 + 64;
                     int c;
                     if (long_record) c = 5;
-                    else if (need <= pool0) c = 0;
+                    else if (need <= cap0) c = 0;
                     else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
                     if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c == 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
                     if (c == 5 && need > gneed) gneed = need;
@@ -932,6 +954,7 @@ void bvg_close(bvg_graph* g) {
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->tr_ws) (void)hipFree(g->tr_ws);
     if (g->dr_ws) (void)hipFree(g->dr_ws);
+    if (g->flow_ws) (void)hipFree(g->flow_ws);
     if (g->d_acc) (void)hipFree(g->d_acc);
     if (g->d_fail) (void)hipFree(g->d_fail);
     if (g->slow_ws) (void)hipFree(g->slow_ws);

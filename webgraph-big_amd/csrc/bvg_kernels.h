@@ -82,6 +82,12 @@ size_t rows_wg_static_lds(int nw);
 // the streaming data-flow kernel (bvg_stream.hip): fast path; lds_pool_elems must be a power of two
 void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 
+// the flow scan kernel (bvg_flow.hip): tier 0 of full scans with default codings and 32-bit successors.  Persistent: `waves`
+// wavefronts take the nblocks blocks in turn, each with flow_scratch_bytes_per_wave(window) bytes of `scratch`.
+size_t flow_scratch_bytes_per_wave(int window);
+size_t flow_lds_bytes(uint32_t ring_cap);
+void launch_flow_scan(const DecodeArgs& a, uint32_t nblocks, uint32_t waves, void* scratch, uint32_t ring_cap, hipStream_t s);
+
 // sums the result stripes into stripe 0 (one workgroup)
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);
 // thread per node: outdegree (BVG:821-842)

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     constexpr bool LEAN = !MAT;                              // scan mode: unreferenced lists are not materialised
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
-    __syncthreads();
+    wave_sync();
 
     uint32_t pool_used = 0;
     uint64_t stg_bit0 = 0; uint32_t stg_bits = 0;             // staged window (wave-uniform)
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             }
             if (livelane) nd_base[(uint32_t)y & RM] = nbase;
             pool_used = lane_get(nincl, 63);
-            __syncthreads();
+            wave_sync();
         };
         if (OVL) {
             if (pool_used > 0) compact();                                     // every row starts from the window lists alone
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             const uint64_t row_lo = lane_get64(off_x, 0);
             const uint64_t row_hi = lane_get64(rec_end, left - 1);
             if (!(row_lo >= stg_bit0 && row_hi + 96 <= stg_bit0 + stg_bits)) {
-                __syncthreads();
+                wave_sync();
                 const uint64_t b0 = (row_lo >> 3) & ~15ull;
                 uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
                 if (nb > (stage_bits >> 3)) nb = stage_bits >> 3;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     *reinterpret_cast<uint4*>(&stage_w[c << 2]) = w;
                 }
                 stg_bit0 = b0 << 3; stg_bits = (uint32_t)(nb << 3);
-                __syncthreads();
+                wave_sync();
             }
         }
         // rows are cut where the records stop fitting the window (the next row restages from there)
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             if (k == 0) k = 1;                                                // the exact check follows the header parse
         }
         if (needed && lane < k) nd_d[(uint32_t)x & RM] = d;
-        __syncthreads();
+        wave_sync();
 
         BVG_T1(6, tq5);
         const uint32_t tq7 = BVG_T0();
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
                     if (shortt && ss >= p0 && ss < p0 + RP) rtmap[ss - p0] = lane | (cntE << 8);
                 }
-                __syncthreads();
+                wave_sync();
                 bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tlast[RU]; T r[RU];
 #pragma unroll
                 for (uint32_t u = 0; u < RU; u++) {
@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
 #pragma unroll
                 for (uint32_t u = 0; u < RU; u++)
                     if (tlast[u] && cnt[u] && trel[u] != tpend[u] && !tbad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
-                __syncthreads();
+                wave_sync();
             }
             };
             // two chains per lane only when the row has the tasks to fill them: a half-empty second chain doubles the instructions of
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             if (rel != pend && !bad && !(a.dbg & 7u)) err |= ERR_MALFORMED;         // SURVEY A.6 self-check
         } else if (act && d == 0 && rel != pend && !bad) err |= ERR_MALFORMED;
         if (ballot(bad && lane < k)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
-        __syncthreads();
+        wave_sync();
 
         // ------------------------------------------------------------------ phase 2: data-flow emission
         const bool rep = act && x >= rep_lo && x < rep_hi;
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             const uint32_t q1 = is >= p0 + 64u ? 0u : (is + In > p0 + 64u ? p0 + 64u - is : In);
                             for (uint32_t q = q0; q < q1; q++) tmap[is + q - p0] = lane | (q << 8);
                         }
-                        __syncthreads();
+                        wave_sync();
                         const bool tl = p0 + lane < Itot;
                         const uint32_t ent = tl ? tmap[lane] : lane;
                         const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             pe = eb + t;
                             if (pe + len > t_d) { zbad = true; pe = 0; len = 0; }
                         }
-                        __syncthreads();                                      // the parked values have been read: positions may replace them
+                        wave_sync();                                      // the parked values have been read: positions may replace them
                         if (tl && len) {
                             if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
                             else {
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             }
                         }
                         cnt_seek++;
-                        __syncthreads();
+                        wave_sync();
                     }
                 }
                 BVG_T1(3, tq1);
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                         const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
                         for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
                     }
-                    __syncthreads();
+                    wave_sync();
                     const bool tl = p0 + lane < Ttot;
                     const uint32_t ent = tl ? tmap[lane] : lane;
                     const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             p++;
                         }
                     }
-                    __syncthreads();
+                    wave_sync();
                     BVG_T1(4, tq4);
                 }
             }
@@ -707,7 +707,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                         const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
                         for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
                     }
-                    __syncthreads();
+                    wave_sync();
                     const bool tl = p0 + lane < Ttot;
                     const uint32_t ent = tl ? tmap[lane] : lane;
                     const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     }
                     blk_chk += csum;
                     BVG_T1(11, tqL2);
-                    __syncthreads();
+                    wave_sync();
                 }
             }
             BVG_T1(10, tqL);
@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         }
         if (!by_tasks) {
             produced[lane] = act ? 0u : kInf;
-            __syncthreads();
+            wave_sync();
             T* const out = pool + base;
             const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; uint32_t rlane = lane; bool samerow = false;
             if (act && ref > 0) {
@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
 
         // ------------------------------------------------------------------ materialise: coalesced copy-out
         if (MAT) {
-            __syncthreads();
+            wave_sync();
             const uint64_t repmask = ballot(rep);
             if (repmask) {
                 const int la = __ffsll((unsigned long long)repmask) - 1;
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 if (rep && a.outdeg && !a.batch) a.outdeg[x - a.from] = (int32_t)d;
             }
         }
-        __syncthreads();
+        wave_sync();
         // next row: lanes shift by k; reuse the prefetched offsets
         cnt_rows++;
         r0 += k;
