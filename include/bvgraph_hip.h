@@ -208,6 +208,17 @@ int bvg_labels_decode_range_lists(bvg_labels* l, int64_t from, int64_t to, const
 /* Same as bvg_labels_decode_range, outdegrees (int32) and labels (int32) in device memory: chains with bvg_decode_range_dev without leaving HBM. */
 int bvg_labels_decode_range_dev(bvg_labels* l, int64_t from, int64_t to, const void* d_outdeg, void* d_labels, uint64_t cap, uint64_t* n_labels);
 
+/* ---- the compressor on the device (second half): BVGraph.store (BVG:2329-2470; CompressionThread.call
+ * :2216-2327, diffComp :1977-2159, intervalize :1595-1618) from an adjacency in CSR form -- adj_off[nodes+1], adj[adj_off[nodes]] with
+ * strictly increasing successor lists -- to the bytes of basename.graph and the nodes+1 bit offsets (write basename.offsets from them
+ * with the gamma / delta coded gaps of BVG:2228,2311).  p gives windowsize, maxrefcount (-1 = unbounded), minintervallength, zetak and
+ * the codings (nodes / arcs are ignored).  chunk_nodes > 0 compresses ranges of that many nodes with a fresh window each, as the
+ * reference's multi-threaded store does (BVG:2404-2457); 0 = one range = the single-threaded store, byte for byte.
+ * *graph / *offsets are malloc'ed (bvg_free).  BVG_E_ARG for lists that are not strictly increasing or leave [0, nodes). */
+int bvg_store(const bvg_params* p, int64_t nodes, const uint64_t* adj_off, const int64_t* adj, int64_t chunk_nodes, int device,
+              uint8_t** graph, uint64_t* graph_bytes, uint64_t** offsets);
+void bvg_free(void* p);
+
 /* ---- synthetic-workload helper (bench only): K back-to-back copies of the graph ----
  * BV records are translation invariant (every value is coded relative to the node id, Appendix A.3
  * of SURVEY.md), so the concatenation of K copies of the bit stream is a valid BVGraph with K*nodes

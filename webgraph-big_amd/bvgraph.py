@@ -115,6 +115,8 @@ def lib():
         L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
         L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_host_alloc.argtypes = [C.c_size_t]; L.bvg_host_alloc.restype = vp
+        L.bvg_store.argtypes = [C.POINTER(Params), i64, vp, vp, i64, C.c_int, pp, C.POINTER(u64), pp]
+        L.bvg_free.argtypes = [vp]; L.bvg_free.restype = None
         L.bvg_host_free.argtypes = [vp]; L.bvg_host_free.restype = None
         L.bvg_split_by_bits.argtypes = [vp, C.c_int, vp]
         L.bvg_split_by_arcs.argtypes = [vp, C.c_int, vp]
@@ -142,6 +144,29 @@ def lib():
             raise ImportError("libbvgraph_hip.so ABI mismatch")
         _LIB = L
     return _LIB
+
+
+def store(adj, params=None, chunk_nodes=0, device=0):
+    """BVGraph.store on the device (bvg_store): adj = (adj_off uint64[n+1], succ int64[m]) or a list of sorted lists.
+    Returns (graph uint8[], offsets uint64[n+1]); byte for byte what the reference's compressor writes."""
+    if isinstance(adj, tuple):
+        off = np.ascontiguousarray(adj[0], dtype=np.uint64); succ = np.ascontiguousarray(adj[1], dtype=np.int64)
+    else:
+        off = np.zeros(len(adj) + 1, dtype=np.uint64)
+        if len(adj):
+            off[1:] = np.cumsum([len(l) for l in adj], dtype=np.uint64)
+        succ = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int64) for l in adj]) if len(adj) and off[-1] else np.empty(0, np.int64), dtype=np.int64)
+    n = len(off) - 1
+    p = params if params is not None else _abi.default_params()
+    g = C.c_void_p(); o = C.c_void_p(); nb = C.c_uint64()
+    sb = succ if len(succ) else np.zeros(1, np.int64)
+    _check(lib().bvg_store(C.byref(p), n, off.ctypes.data, sb.ctypes.data, chunk_nodes, device, C.byref(g), C.byref(nb), C.byref(o)), "store")
+    try:
+        graph = np.ctypeslib.as_array(C.cast(g, C.POINTER(C.c_uint8)), shape=(max(int(nb.value), 1),))[:int(nb.value)].copy()
+        offsets = np.ctypeslib.as_array(C.cast(o, C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+    finally:
+        lib().bvg_free(g); lib().bvg_free(o)
+    return graph, offsets
 
 
 def parse_properties(text):

@@ -1391,6 +1391,35 @@ int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) { return gu
 int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_arcs_impl(g, k, bounds); }); }
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_bits_impl(g, k, bounds); }); }
 
+// BVGraph.store(graph, basename, W, maxRef, minInterval, zetaK, flags) on the device (BVG:2329-2470 around CompressionThread.call,
+// :2216-2327): see bvg_encode.hip.  Host buffers in, malloc'ed host buffers out.
+int bvg_store(const bvg_params* p, int64_t nodes, const uint64_t* adj_off, const int64_t* adj, int64_t chunk_nodes, int device,
+              uint8_t** graph, uint64_t* graph_bytes, uint64_t** offsets) {
+    if (!p || !adj_off || !graph || !graph_bytes || !offsets || nodes < 0) return BVG_E_ARG;
+    return guarded([&]() -> int {
+        bvg_params q = *p; q.nodes = nodes;
+        int r = check_params(q); if (r) return r;
+        r = ensure_device(device); if (r) return r;
+        const uint64_t m = adj_off[nodes];
+        if (m && !adj) return BVG_E_ARG;
+        uint64_t* d_off = nullptr; int64_t* d_adj = nullptr; uint8_t* d_graph = nullptr; uint64_t* d_offsets = nullptr;
+        auto done = [&](int code) { for (void* x : {(void*)d_off, (void*)d_adj, (void*)d_graph, (void*)d_offsets}) if (x) (void)hipFree(x); return code; };
+        if (hipMalloc(&d_off, ((size_t)nodes + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&d_adj, (size_t)(m ? m : 1) * sizeof(int64_t)) != hipSuccess) { (void)hipGetLastError(); return done(BVG_E_NOMEM); }
+        if (hipMemcpy(d_off, adj_off, ((size_t)nodes + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return done(BVG_E_HIP);
+        if (m && hipMemcpy(d_adj, adj, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return done(BVG_E_HIP);
+        uint64_t nbytes = 0;
+        r = encode_store_dev(q, d_off, d_adj, nodes, chunk_nodes, nullptr, &d_graph, &nbytes, &d_offsets);
+        if (r) return done(r);
+        uint8_t* hg = (uint8_t*)calloc((size_t)nbytes + 16, 1); uint64_t* ho = (uint64_t*)malloc(((size_t)nodes + 1) * sizeof(uint64_t));
+        if (!hg || !ho) { free(hg); free(ho); return done(BVG_E_NOMEM); }
+        if ((nbytes && hipMemcpy(hg, d_graph, (size_t)nbytes, hipMemcpyDeviceToHost) != hipSuccess) ||
+            hipMemcpy(ho, d_offsets, ((size_t)nodes + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) { free(hg); free(ho); return done(BVG_E_HIP); }
+        *graph = hg; *graph_bytes = nbytes; *offsets = ho;
+        return done(0);
+    });
+}
+void bvg_free(void* p) { free(p); }
+
 uint64_t bvg_arc_mix(uint64_t x, uint64_t y) {
     uint64_t kx = splitmix64(x);
     return mix_keyed((uint32_t)kx, (uint32_t)(kx >> 32) | 1u, y);

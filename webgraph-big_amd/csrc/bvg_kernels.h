@@ -120,6 +120,10 @@ void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t
 int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod, uint64_t* offsets, unsigned* err,
                             hipStream_t s, int* rounds);
 
+// BVGraph.store on the device (bvg_encode.hip): adjacency in CSR form (device pointers) -> .graph bytes + offsets (hipMalloc'ed here)
+int encode_store_dev(const bvg_params& p, const uint64_t* d_adj_off, const int64_t* d_adj, int64_t n, int64_t chunk_nodes, hipStream_t s,
+                     uint8_t** d_graph_out, uint64_t* graph_bytes, uint64_t** d_offsets_out);
+
 // synthetic tiling (bvg_tile)
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
 void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);
