@@ -92,8 +92,12 @@ int bvg_decode_offsets(const uint8_t* obytes, size_t nbytes, int64_t nodes, int 
 int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out);
 /* Same from host memory.  offsets: nodes+1 bit positions or NULL (derive on device). */
 int bvg_open_mem(const bvg_params* p, const uint8_t* graph, uint64_t nbytes, const uint64_t* offsets, int device, bvg_graph** out);
-/* Same from DEVICE memory already resident in HBM (buffers are adopted, not copied; they must stay
- * alive until bvg_close and d_graph must be readable up to nbytes rounded up to 16 + 16 bytes). */
+/* Same from DEVICE memory already resident in HBM.  d_graph is adopted, not copied: it must stay
+ * alive until bvg_close and be readable up to nbytes rounded up to 16 + 16 bytes.  d_offsets
+ * (nodes+1 uint64) is read once: the library keeps its own packed index (4 bytes per node + 8 per
+ * 1024 nodes, the counterpart of the Elias-Fano list of BVG:1545-1558) and the caller may free the
+ * array when the call returns -- except when 1024 consecutive records span 2^32 bits or more (or
+ * BVG_WIDE_OFFSETS=1 is set): then the plain array is used in place and must stay alive. */
 int bvg_open_dev(const bvg_params* p, const void* d_graph, uint64_t nbytes, const void* d_offsets, int device, bvg_graph** out);
 /* BVGraph.copy() (BVG:553-578): flyweight sharing the immutable device data, with its own stream
  * and workspace, usable from another thread. */

@@ -40,6 +40,15 @@ namespace {
 constexpr uint32_t kDefaultBlockBits = 32768;   // ~4 KiB of compressed stream per wavefront
 constexpr uint64_t kPad = 64;                   // zero bytes after the stream (8-byte loads + record overruns)
 
+// a device allocation freed on every return path
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default; DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    int alloc(size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 1) == hipSuccess) return 0; p = nullptr; (void)hipGetLastError(); return 1; }
+    void* release() { void* q = p; p = nullptr; return q; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 struct Plan {
     uint32_t block_bits = 0;
     uint32_t nblk = 0;
@@ -49,7 +58,7 @@ struct Plan {
     uint64_t version = 0;
     // residual skip index (built by two passes of the row kernel the first time a large range is decoded)
     std::atomic<int> skip_state{0};           // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index); published with release order
-    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint32_t* d_skip_bit = nullptr; void* d_skip_val = nullptr;
+    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint16_t* d_skip_bit = nullptr; void* d_skip_val = nullptr;
     bool skip_wide = false;                   // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
     std::vector<uint64_t> h_skip_first;
     void release_skip() {
@@ -76,7 +85,10 @@ struct Shared {
     int device = 0;
     bvg_params p{};
     uint8_t* d_graph = nullptr; uint64_t nbytes = 0; uint64_t padded = 0; bool own_graph = false;
-    uint64_t* d_offsets = nullptr; bool own_offsets = false;
+    // the offsets index: packed (owned: 4 bytes per node + 8 per 2^kOffShift nodes) or, as a fallback, the plain 64-bit array
+    Offsets offs{nullptr, nullptr, nullptr};
+    uint32_t* d_off_lo = nullptr; uint64_t* d_off_hi = nullptr; uint64_t* d_off_wide = nullptr; bool own_wide = false;
+    uint64_t offsets_bytes() const { return offs.lo ? ((uint64_t)p.nodes + 1) * 4 + ((((uint64_t)p.nodes + 1) >> kOffShift) + 1) * 8 : ((uint64_t)p.nodes + 1) * 8; }
     uint64_t total_bits = 0;
     bool wide = false;
     // Block plans are immutable once built and shared by reference count: a handle holds the one it decodes with for the whole
@@ -201,7 +213,9 @@ void release_shared(Shared* sh) {
     (void)hipSetDevice(sh->device);
     sh->plans.clear();
     if (sh->own_graph && sh->d_graph) (void)hipFree(sh->d_graph);
-    if (sh->own_offsets && sh->d_offsets) (void)hipFree(sh->d_offsets);
+    if (sh->d_off_lo) (void)hipFree(sh->d_off_lo);
+    if (sh->d_off_hi) (void)hipFree(sh->d_off_hi);
+    if (sh->own_wide && sh->d_off_wide) (void)hipFree(sh->d_off_wide);
     delete sh;
 }
 
@@ -233,7 +247,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
     if (nb > 0x7FFFFFF0ull) return BVG_E_UNSUPPORTED;
     uint64_t* d_first0 = nullptr;
     HIPCHK(hipMalloc(&d_first0, (nb + 1) * sizeof(uint64_t)));
-    launch_plan_boundaries(sh->d_offsets, n, block_bits, nb, d_first0, g->stream);
+    launch_plan_boundaries(sh->offs, n, block_bits, nb, d_first0, g->stream);
     std::vector<uint64_t> first(nb + 1);
     HIPCHK(hipMemcpyAsync(first.data(), d_first0, (nb + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
@@ -251,7 +265,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
         HIPCHK(hipMalloc(&d_halo, (size_t)nblk * sizeof(uint32_t)));
         HIPCHK(hipMalloc(&d_mask, (size_t)nblk * sizeof(uint64_t)));
         HIPCHK(hipMemcpyAsync(d_first, uniq.data(), (nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
-        launch_plan_halo(sh->d_graph, limit, sh->d_offsets, n, d_first, nblk, sh->p.window_size, codings_of(sh->p), d_halo, d_mask, g->stream);
+        launch_plan_halo(sh->d_graph, limit, sh->offs, n, d_first, nblk, sh->p.window_size, codings_of(sh->p), d_halo, d_mask, g->stream);
         std::vector<uint32_t> halo(nblk);
         HIPCHK(hipMemcpyAsync(halo.data(), d_halo, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
@@ -264,7 +278,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
             {   // per-block largest outdegree (one wavefront per block), kept on the host to predict tiers
                 uint32_t* d_maxd = nullptr;
                 HIPCHK(hipMalloc(&d_maxd, (size_t)nblk * sizeof(uint32_t)));
-                launch_plan_maxd(sh->d_graph, limit, sh->d_offsets, d_first, d_halo, nblk, sh->p.outdegree_coding, sh->p.window_size, d_maxd, g->stream);
+                launch_plan_maxd(sh->d_graph, limit, sh->offs, d_first, d_halo, nblk, sh->p.outdegree_coding, sh->p.window_size, d_maxd, g->stream);
                 plan.h_maxd.resize(nblk);
                 hipError_t e2 = hipMemcpyAsync(plan.h_maxd.data(), d_maxd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
                 if (e2 == hipSuccess) e2 = hipStreamSynchronize(g->stream);
@@ -320,7 +334,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp) {
     for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + cnt[i];
     const uint64_t total = first[nblk];
     if (total == 0) { pl.skip_state.store(1, std::memory_order_release); return 0; }
-    if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint32_t)) != hipSuccess ||
+    if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint16_t) + 16) != hipSuccess ||
         hipMalloc(&pl.d_skip_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); (void)hipGetLastError(); return 0; }
     if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
     pl.skip_total = total; pl.skip_wide = build_wide;
@@ -330,7 +344,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp) {
     if (r) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
     pl.h_skip_first.swap(first);
     pl.skip_state.store(1, std::memory_order_release);
-    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * (build_wide ? 12.0 : 8.0) / 1048576.0);
+    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0);
     return 0;
 }
 
@@ -368,7 +382,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     HIPCHK(hipMemsetAsync(g->d_fail, 0, sizeof(uint32_t), g->stream));
 
     DecodeArgs a{};
-    a.graph = sh->d_graph; a.limit_byte = sh->nbytes; a.padded_bytes = sh->padded; a.offsets = sh->d_offsets; a.n = sh->p.nodes;
+    a.graph = sh->d_graph; a.limit_byte = sh->nbytes; a.padded_bytes = sh->padded; a.offsets = sh->offs; a.n = sh->p.nodes;
     a.from = from; a.to = to;
     a.blk_first = batch ? batch->d_first : pl.d_first; a.blk_halo = batch ? batch->d_halo : pl.d_halo; a.blk_mask = batch ? batch->d_mask : pl.d_mask;
     a.work_list = nullptr; a.blk_lo = lo; a.batch = batch ? 1u : 0u;
@@ -407,7 +421,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         while (words < 1024 && (double)words * 32.0 < bits_per_node * 64.0 * 1.5) words *= 2;
         a.lds_stage_words = words;
     }
-    if (getenv("BVG_STAGE")) a.lds_stage_words = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u, 64u), 4096u);
+    if (getenv("BVG_STAGE")) a.lds_stage_words = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u, 64u), 2048u);   // (the skip entries hold 16-bit offsets into a record)
 
     // Workgroup variant of the row kernel (several wavefronts share one pool): scan mode, default codings, 32-bit successors
     int wg_nw = 0;
@@ -730,8 +744,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;
-        res->index_bytes = (uint64_t)(to - from + 1) * 8 + (uint64_t)nblocks * 20;
-        if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * (4 + esz) + (uint64_t)nblocks * 8;
+        res->index_bytes = (uint64_t)(to - from + 1) * (sh->offs.lo ? 4 : 8) + (sh->offs.lo ? ((uint64_t)(to - from) >> kOffShift) * 8 : 0) + (uint64_t)nblocks * 20;
+        if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * (2 + esz) + (uint64_t)nblocks * 8;
         res->graph_bytes = 0;
     }
     if (acc[3] && getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] error bits 0x%llx\n", acc[3]);
@@ -740,8 +754,46 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     return 0;
 }
 
+// one entry of the index on the host
+int read_offset(const Shared* sh, int64_t x, uint64_t* out) {
+    if (!sh->offs.lo) { HIPCHK(hipMemcpy(out, sh->offs.wide + x, sizeof(uint64_t), hipMemcpyDeviceToHost)); return 0; }
+    uint32_t lo = 0; uint64_t hi = 0;
+    HIPCHK(hipMemcpy(&lo, sh->offs.lo + x, sizeof lo, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&hi, sh->offs.hi + (x >> kOffShift), sizeof hi, hipMemcpyDeviceToHost));
+    *out = hi + lo;
+    return 0;
+}
+
+// Packs the index (n+1 entries; on the device or on the host) into sh->offs.  1 = a distance does not fit 32 bits: the caller keeps
+// the plain array.  A host array is staged through a 128 MiB device buffer, so the plain form never exists in HBM.
+int pack_offsets(Shared* sh, const uint64_t* src_dev, const uint64_t* src_host) {
+    const int64_t n1 = sh->p.nodes + 1, G = (int64_t)1 << kOffShift;
+    DevBuf lo, hi, ovf, stagebuf;
+    if (lo.alloc((size_t)n1 * sizeof(uint32_t)) || hi.alloc((size_t)((n1 + G - 1) / G + 1) * sizeof(uint64_t)) || ovf.alloc(sizeof(unsigned))) return BVG_E_NOMEM;
+    HIPCHK(hipMemset(ovf.p, 0, sizeof(unsigned)));
+    if (src_dev) launch_pack_offsets(src_dev, 0, n1, (uint32_t*)lo.p, (uint64_t*)hi.p, (unsigned*)ovf.p, nullptr);
+    else {
+        const int64_t step = (int64_t)1 << 24;
+        if (stagebuf.alloc((size_t)std::min<int64_t>(step, n1) * sizeof(uint64_t))) return BVG_E_NOMEM;
+        for (int64_t first = 0; first < n1; first += step) {
+            const int64_t cnt = std::min<int64_t>(step, n1 - first);
+            HIPCHK(hipMemcpy(stagebuf.p, src_host + first, (size_t)cnt * sizeof(uint64_t), hipMemcpyHostToDevice));
+            launch_pack_offsets((const uint64_t*)stagebuf.p, first, cnt, (uint32_t*)lo.p, (uint64_t*)hi.p, (unsigned*)ovf.p, nullptr);
+            HIPCHK(hipStreamSynchronize(nullptr));
+        }
+    }
+    unsigned o = 0;
+    HIPCHK(hipMemcpy(&o, ovf.p, sizeof o, hipMemcpyDeviceToHost));
+    if (o) return 1;
+    sh->d_off_lo = (uint32_t*)lo.release(); sh->d_off_hi = (uint64_t*)hi.release();
+    sh->offs = Offsets{sh->d_off_lo, sh->d_off_hi, nullptr};
+    return 0;
+}
+
+struct PackedOffsets { uint32_t* lo; uint64_t* hi; };   // bvg_tile hands over an index it wrote in packed form
+
 int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph_in, uint64_t nbytes, const uint64_t* h_offsets,
-                const void* d_offsets_in, int device, bvg_graph** out) {
+                const void* d_offsets_in, int device, bvg_graph** out, const PackedOffsets* packed = nullptr) {
     if (!p || !out) return BVG_E_ARG;
     int r = check_params(*p); if (r) return r;
     r = ensure_device(device); if (r) return r;
@@ -758,12 +810,27 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
         HIPCHK(hipMemset(sh->d_graph, 0, padded));
         if (nbytes) HIPCHK(hipMemcpy(sh->d_graph, h_graph, nbytes, hipMemcpyHostToDevice));
     }
-    if (d_offsets_in) { sh->d_offsets = (uint64_t*)d_offsets_in; sh->own_offsets = false; }
-    else {
-        HIPCHK(hipMalloc(&sh->d_offsets, ((size_t)n + 1) * sizeof(uint64_t)));
-        sh->own_offsets = true;
-        if (h_offsets) HIPCHK(hipMemcpy(sh->d_offsets, h_offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
-        else {
+    // The index is kept packed (bvg_kernels.h: Offsets).  A caller's device array is packed into memory of our own and not referenced
+    // afterwards; BVG_WIDE_OFFSETS=1 or a distance that does not fit 32 bits keeps the plain 64-bit form.
+    const bool keep_wide = getenv("BVG_WIDE_OFFSETS") != nullptr;
+    if (packed) { sh->d_off_lo = packed->lo; sh->d_off_hi = packed->hi; sh->offs = Offsets{packed->lo, packed->hi, nullptr}; }
+    else if (d_offsets_in) {
+        int pk = keep_wide ? 1 : pack_offsets(sh, (const uint64_t*)d_offsets_in, nullptr);
+        if (pk < 0) { release_shared(sh); return pk; }
+        if (pk) { sh->d_off_wide = (uint64_t*)d_offsets_in; sh->own_wide = false; sh->offs = Offsets{nullptr, nullptr, sh->d_off_wide}; }
+    } else if (h_offsets) {
+        int pk = keep_wide ? 1 : pack_offsets(sh, nullptr, h_offsets);
+        if (pk < 0) { release_shared(sh); return pk; }
+        if (pk) {
+            HIPCHK(hipMalloc(&sh->d_off_wide, ((size_t)n + 1) * sizeof(uint64_t)));
+            sh->own_wide = true; sh->offs = Offsets{nullptr, nullptr, sh->d_off_wide};
+            HIPCHK(hipMemcpy(sh->d_off_wide, h_offsets, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+        }
+    } else {
+        uint64_t* d_wide = nullptr;
+        HIPCHK(hipMalloc(&d_wide, ((size_t)n + 1) * sizeof(uint64_t)));
+        sh->d_off_wide = d_wide; sh->own_wide = true; sh->offs = Offsets{nullptr, nullptr, d_wide};
+        {
             // no .offsets (loadSequential / loadOffline, BVG:1345-1464; BVGraph -O, BVG:2595-2609): derive the index from
             // the stream itself with one sequential pass on the device
             unsigned* d_err = nullptr;
@@ -774,23 +841,26 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
             // 0.7-17x the speed of the one-wavefront walk depending on the graph (profiles/r02/derive_bench.py).  Default and fall-back
             // (windows > 64, records > 64 Mbit, any error, so that the error bits are those of the plain walk): the sequential walk.
             int rounds = 0;
-            int pr = !getenv("BVG_DERIVE_PAR") ? -1 : derive_offsets_parallel(sh->d_graph, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), sh->d_offsets, d_err, nullptr, &rounds);
+            int pr = !getenv("BVG_DERIVE_PAR") ? -1 : derive_offsets_parallel(sh->d_graph, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr, &rounds);
             if (pr == 0) {
                 unsigned e0 = 0;
                 if (hipMemcpy(&e0, d_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_err); release_shared(sh); return BVG_E_HIP; }
                 if (e0) { pr = -4; (void)hipMemset(d_err, 0, sizeof(unsigned)); }
             }
             if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] derive offsets: parallel walk %s (%d rounds)\n", pr == 0 ? "ok" : "not used / failed", rounds);
-            if (pr != 0) launch_derive_offsets(sh->d_graph, sh->padded, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), sh->d_offsets, d_err, nullptr);
+            if (pr != 0) launch_derive_offsets(sh->d_graph, sh->padded, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr);
             unsigned herr = 0;
             hipError_t e = hipMemcpy(&herr, d_err, sizeof(unsigned), hipMemcpyDeviceToHost);
             (void)hipFree(d_err);
             if (e != hipSuccess) { release_shared(sh); return BVG_E_HIP; }
-            if (getenv("BVG_DEBUG")) { uint64_t last = 0; (void)hipMemcpy(&last, sh->d_offsets + n, 8, hipMemcpyDeviceToHost); fprintf(stderr, "[bvg] derive offsets: err=%u end=%llu of %llu bits\n", herr, (unsigned long long)last, (unsigned long long)nbytes * 8); }
+            if (getenv("BVG_DEBUG")) { uint64_t last = 0; (void)hipMemcpy(&last, d_wide + n, 8, hipMemcpyDeviceToHost); fprintf(stderr, "[bvg] derive offsets: err=%u end=%llu of %llu bits\n", herr, (unsigned long long)last, (unsigned long long)nbytes * 8); }
             if (herr) { release_shared(sh); return (herr & ERR_REF_RANGE) ? BVG_E_STATE : BVG_E_EOF; }
         }
+        int pk = keep_wide ? 1 : pack_offsets(sh, d_wide, nullptr);
+        if (pk < 0) { release_shared(sh); return pk; }
+        if (pk == 0) { (void)hipFree(d_wide); sh->d_off_wide = nullptr; sh->own_wide = false; }
     }
-    HIPCHK(hipMemcpy(&sh->total_bits, sh->d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    r = read_offset(sh, n, &sh->total_bits); if (r) { release_shared(sh); return r; }
     if (sh->total_bits > nbytes * 8) { release_shared(sh); return BVG_E_EOF; }
     r = make_handle(sh, out);
     if (r) { release_shared(sh); return r; }
@@ -972,7 +1042,17 @@ int bvg_set_tuning(bvg_graph* g, const bvg_tuning* t) { if (!g || !t) return BVG
 int bvg_get_offsets(bvg_graph* g, uint64_t* out) {
     if (!g || !out) return BVG_E_ARG;
     HIPCHK(hipSetDevice(g->sh->device));
-    HIPCHK(hipMemcpy(out, g->sh->d_offsets, ((size_t)g->sh->p.nodes + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const Shared* sh = g->sh; const int64_t n1 = sh->p.nodes + 1;
+    if (!sh->offs.lo) { HIPCHK(hipMemcpy(out, sh->offs.wide, (size_t)n1 * sizeof(uint64_t), hipMemcpyDeviceToHost)); return 0; }
+    DevBuf tmp;                                                        // unpacked in pieces through a 128 MiB device buffer
+    const int64_t step = (int64_t)1 << 24;
+    if (tmp.alloc((size_t)std::min<int64_t>(step, n1) * sizeof(uint64_t))) return BVG_E_NOMEM;
+    for (int64_t first = 0; first < n1; first += step) {
+        const int64_t cnt = std::min<int64_t>(step, n1 - first);
+        launch_unpack_offsets(sh->offs, first, cnt, (uint64_t*)tmp.p, g->stream);
+        HIPCHK(hipStreamSynchronize(g->stream));
+        HIPCHK(hipMemcpy(out + first, tmp.p, (size_t)cnt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -983,7 +1063,7 @@ int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out) {
     HIPCHK(hipSetDevice(g->sh->device));
     int32_t* d = nullptr;
     HIPCHK(hipMalloc(&d, (size_t)(to - from) * sizeof(int32_t)));
-    launch_outdegrees(g->sh->d_graph, g->sh->nbytes, g->sh->d_offsets, from, to, g->sh->p.outdegree_coding, d, nullptr, g->stream);
+    launch_outdegrees(g->sh->d_graph, g->sh->nbytes, g->sh->offs, from, to, g->sh->p.outdegree_coding, d, nullptr, g->stream);
     hipError_t e = hipMemcpyAsync(out, d, (size_t)(to - from) * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
     (void)hipFree(d);
@@ -1020,7 +1100,7 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
     auto at = [&](size_t off) { return (char*)g->dr_ws + off; };
     int32_t* d_deg = (dev && outdeg) ? outdeg : (int32_t*)at(o_deg);
     uint64_t* d_cum = (uint64_t*)at(o_cum);
-    launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
+    launch_outdegrees(sh->d_graph, sh->nbytes, sh->offs, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
     launch_exclusive_scan(d_deg, d_cum, cnt, (uint64_t*)at(o_tmp), g->stream);
     uint64_t total = 0;
     HIPCHK(hipMemcpyAsync(&total, d_cum + cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
@@ -1036,7 +1116,7 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
             // growing moves the workspace: the prefix sums are recomputed rather than copied (two tiny kernels)
             rc = dr_ensure(g, o_succ + (size_t)(total ? total : 1) * sizeof(int64_t)); if (rc) return rc;
             d_deg = (int32_t*)at(o_deg); d_cum = (uint64_t*)at(o_cum);
-            launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
+            launch_outdegrees(sh->d_graph, sh->nbytes, sh->offs, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
             launch_exclusive_scan(d_deg, d_cum, cnt, (uint64_t*)at(o_tmp), g->stream);
         }
         d_succ = (int64_t*)at(o_succ);
@@ -1082,9 +1162,9 @@ static int bvg_successors_batch_impl(bvg_graph* g, const int64_t* nodes, int64_t
     auto at = [&](size_t off) { return (char*)g->dr_ws + off; };
     auto prepare = [&]() -> int {
         HIPCHK(hipMemcpyAsync(at(o_nodes), nodes, c * sizeof(int64_t), hipMemcpyHostToDevice, g->stream));
-        launch_outdegrees_gather(sh->d_graph, sh->nbytes, sh->d_offsets, (const int64_t*)at(o_nodes), count, sh->p.outdegree_coding, (int32_t*)at(o_deg), (uint64_t*)at(o_first), g->stream);
+        launch_outdegrees_gather(sh->d_graph, sh->nbytes, sh->offs, (const int64_t*)at(o_nodes), count, sh->p.outdegree_coding, (int32_t*)at(o_deg), (uint64_t*)at(o_first), g->stream);
         launch_exclusive_scan((const int32_t*)at(o_deg), (uint64_t*)at(o_cum), count, (uint64_t*)at(o_tmp), g->stream);
-        launch_plan_halo(sh->d_graph, sh->nbytes, sh->d_offsets, sh->p.nodes, (const uint64_t*)at(o_first), (uint32_t)(2 * count), sh->p.window_size, codings_of(sh->p), (uint32_t*)at(o_halo), (uint64_t*)at(o_mask), g->stream);
+        launch_plan_halo(sh->d_graph, sh->nbytes, sh->offs, sh->p.nodes, (const uint64_t*)at(o_first), (uint32_t)(2 * count), sh->p.window_size, codings_of(sh->p), (uint32_t*)at(o_halo), (uint64_t*)at(o_mask), g->stream);
         return 0;
     };
     rc = prepare(); if (rc) return rc;
@@ -1120,8 +1200,7 @@ static int bvg_scan_impl(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result
     int r = run_decode(g, from, to, false, nullptr, nullptr, nullptr, out);
     // algorithmic bytes: the compressed bytes covering [from,to)
     uint64_t b[2];
-    HIPCHK(hipMemcpy(&b[0], sh->d_offsets + from, sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&b[1], sh->d_offsets + to, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    { int r2 = read_offset(sh, from, &b[0]); if (!r2) r2 = read_offset(sh, to, &b[1]); if (r2) return r2; }
     out->graph_bytes = (b[1] + 7) / 8 - b[0] / 8;
     return r;
 }
@@ -1155,7 +1234,7 @@ static int transpose_impl(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint
     HIPCHK(hipMemsetAsync(at(o_cum), 0, (nn + 1) * sizeof(uint64_t), g->stream));
     uint64_t total = 0;
     if (n > 0) {
-        launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, 0, n, sh->p.outdegree_coding, (int32_t*)at(o_deg), nullptr, g->stream);
+        launch_outdegrees(sh->d_graph, sh->nbytes, sh->offs, 0, n, sh->p.outdegree_coding, (int32_t*)at(o_deg), nullptr, g->stream);
         launch_exclusive_scan((const int32_t*)at(o_deg), (uint64_t*)at(o_cum), n, (uint64_t*)at(o_tmp), g->stream);
         HIPCHK(hipMemcpyAsync(&total, (uint64_t*)at(o_cum) + n, sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
     }
@@ -1263,12 +1342,12 @@ static int bvg_split_by_arcs_impl(bvg_graph* g, int k, int64_t* bounds) {
     auto done = [&](int code) { for (void* p : {(void*)d_deg, (void*)d_cum, (void*)d_tmp, (void*)d_first}) if (p) (void)hipFree(p); return code; };
     if (hipMalloc(&d_deg, (size_t)n * 4) != hipSuccess || hipMalloc(&d_cum, (size_t)(n + 1) * 8) != hipSuccess ||
         hipMalloc(&d_tmp, scan_tmp_elems(n) * 8) != hipSuccess || hipMalloc(&d_first, ((size_t)k + 1) * 8) != hipSuccess) return done(BVG_E_NOMEM);
-    launch_outdegrees(sh->d_graph, sh->nbytes, sh->d_offsets, 0, n, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
+    launch_outdegrees(sh->d_graph, sh->nbytes, sh->offs, 0, n, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
     launch_exclusive_scan(d_deg, d_cum, n, d_tmp, g->stream);
     uint64_t arcs = 0;
     if (hipMemcpyAsync(&arcs, d_cum + n, 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return done(BVG_E_HIP);
     uint64_t per = (arcs + (uint64_t)k - 1) / (uint64_t)k; if (per == 0) per = 1;
-    launch_plan_boundaries(d_cum, n, per, (uint64_t)k, d_first, g->stream);
+    launch_plan_boundaries(Offsets{nullptr, nullptr, d_cum}, n, per, (uint64_t)k, d_first, g->stream);   // (cumulative outdegrees: a plain array)
     std::vector<uint64_t> f((size_t)k + 1);
     if (hipMemcpyAsync(f.data(), d_first, ((size_t)k + 1) * 8, hipMemcpyDeviceToHost, g->stream) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess) return done(BVG_E_HIP);
     for (int i = 0; i <= k; i++) bounds[i] = (int64_t)f[(size_t)i];
@@ -1285,7 +1364,7 @@ static int bvg_split_by_bits_impl(bvg_graph* g, int k, int64_t* bounds) {
     uint64_t per = (sh->total_bits + (uint64_t)k - 1) / (uint64_t)k; if (per == 0) per = 1;
     uint64_t* d_first = nullptr;
     HIPCHK(hipMalloc(&d_first, ((size_t)k + 1) * sizeof(uint64_t)));
-    launch_plan_boundaries(sh->d_offsets, n, per, (uint64_t)k, d_first, g->stream);
+    launch_plan_boundaries(sh->offs, n, per, (uint64_t)k, d_first, g->stream);
     std::vector<uint64_t> f((size_t)k + 1);
     hipError_t e = hipMemcpyAsync(f.data(), d_first, ((size_t)k + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
@@ -1370,17 +1449,20 @@ static int bvg_tile_impl(const bvg_graph* base, int64_t copies, bvg_graph** out)
     const uint64_t total_bits = b->total_bits * (uint64_t)copies;
     const uint64_t nbytes = (total_bits + 7) / 8;
     const uint64_t padded = ((nbytes + 15) & ~15ull) + kPad;
-    uint8_t* d_graph = nullptr; uint64_t* d_off = nullptr;
+    uint8_t* d_graph = nullptr; uint32_t* d_lo = nullptr; uint64_t* d_hi = nullptr;
+    const size_t n1 = (size_t)(n * copies) + 1;
     HIPCHK(hipMalloc(&d_graph, padded));
-    hipError_t e = hipMalloc(&d_off, ((size_t)(n * copies) + 1) * sizeof(uint64_t));
-    if (e != hipSuccess) { (void)hipFree(d_graph); return BVG_E_NOMEM; }
+    if (hipMalloc(&d_lo, n1 * sizeof(uint32_t)) != hipSuccess || hipMalloc(&d_hi, ((n1 >> kOffShift) + 2) * sizeof(uint64_t)) != hipSuccess) {
+        (void)hipFree(d_graph); if (d_lo) (void)hipFree(d_lo); return BVG_E_NOMEM;
+    }
     launch_tile_graph(b->d_graph, b->total_bits, d_graph, padded, copies, base->stream);
-    launch_tile_offsets(b->d_offsets, n, b->total_bits, d_off, copies, base->stream);
+    launch_tile_offsets(b->offs, n, b->total_bits, d_lo, d_hi, copies, base->stream);   // (distances fit 32 bits wherever the base's do)
     HIPCHK(hipStreamSynchronize(base->stream));
     bvg_params p = b->p; p.nodes = n * copies; if (p.arcs >= 0) p.arcs *= copies;
-    int r = open_common(&p, nullptr, d_graph, nbytes, nullptr, d_off, b->device, out);
-    if (r) { (void)hipFree(d_graph); (void)hipFree(d_off); return r; }
-    (*out)->sh->own_graph = true; (*out)->sh->own_offsets = true;
+    const PackedOffsets pk{d_lo, d_hi};
+    int r = open_common(&p, nullptr, d_graph, nbytes, nullptr, nullptr, b->device, out, &pk);
+    if (r) { (void)hipFree(d_graph); return r; }                      // (open_common owns the index from the start)
+    (*out)->sh->own_graph = true;
     (*out)->tun = base->tun;
     return 0;
 }

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                         if (tl && q) {
                             const uint64_t en = sk_base + t_ef + q - 1u;
                             trel = t_rec + a.skip_bit[en]; r = reinterpret_cast<const T*>(a.skip_val)[en];
-                            if (!(trel > t_rel && trel < t_pend)) { tbad = true; cnt = 0; trel = 0; }
+                            if (!(trel > t_rel && trel < t_pend) || trel - t_rec == 0xFFFFu) { tbad = true; cnt = 0; trel = 0; }
                         }
                         for (uint32_t i = 0;; i++) {
                             const bool on = i < cnt;

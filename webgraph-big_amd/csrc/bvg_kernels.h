@@ -30,10 +30,22 @@ constexpr int kRingBig = 2048;
 constexpr int kMaxWindowBig = kRingBig - 64;
 constexpr int kMaxHaloBig = 8192;
 
+// Offsets index in HBM, packed: one 64-bit base per 2^kOffShift nodes + a 32-bit distance per node (4 bytes per node instead of
+// the 8 of a plain array; the reference keeps it as an Elias-Fano list, BVG:1545-1558).  `wide` is the plain form: the fallback
+// when 2^kOffShift consecutive records span 2^32 bits or more, and BVG_WIDE_OFFSETS=1.
+constexpr int kOffShift = 10;
+struct Offsets {
+    const uint32_t* lo; const uint64_t* hi; const uint64_t* wide;
+    __host__ __device__ __forceinline__ uint64_t operator[](int64_t x) const { return lo ? hi[x >> kOffShift] + lo[x] : wide[x]; }
+};
+// packs entries [first, first + count) of an index (first: a multiple of 2^kOffShift; src[0] is entry `first`); *overflow != 0 if a distance does not fit
+void launch_pack_offsets(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow, hipStream_t s);
+void launch_unpack_offsets(Offsets o, int64_t first, int64_t count, uint64_t* dst, hipStream_t s);
+
 struct DecodeArgs {
     const uint8_t* graph; uint64_t limit_byte;
     uint64_t padded_bytes;              // readable bytes of `graph` (multiple of 16)
-    const uint64_t* offsets;            // n+1 bit positions
+    Offsets offsets;                    // n+1 bit positions
     int64_t n;
     int64_t from, to;                   // only nodes in [from,to) are reported
     const uint64_t* blk_first;          // nblk+1 node ids
@@ -67,7 +79,7 @@ struct DecodeArgs {
     // {bit offset of that residual's code from the record start, value of the residual before it}; entries of a block
     // are contiguous, in node order.  skip_mode 1 = count entries per block, 2 = fill them, 0 = use them when present.
     const uint64_t* skip_first;         // nblk+1 entry indices, or nullptr
-    uint32_t* skip_bit; void* skip_val; // entries (skip_val: one successor-typed value per entry, 4 or 8 bytes)
+    uint16_t* skip_bit; void* skip_val; // entries: 16-bit bit offset (a record that uses the index fits the LDS window, <= 64 Kbit) + one successor-typed value (4 or 8 bytes)
     uint32_t* skip_cnt;                 // skip_mode 1: per-block entry count out
     uint32_t skip_mode;
 };
@@ -91,23 +103,23 @@ void launch_flow_scan(const DecodeArgs& a, uint32_t nblocks, uint32_t waves, voi
 // sums the result stripes into stripe 0 (one workgroup)
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);
 // thread per node: outdegree (BVG:821-842)
-void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,
+void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t from, int64_t to,
                        int outdegree_coding, int32_t* out, unsigned long long* total, hipStream_t s);
 // outdegree of an arbitrary list of nodes (random access, BVG:821-842); also writes the two plan entries {x, x+1} per request
-void launch_outdegrees_gather(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const int64_t* nodes, int64_t count,
+void launch_outdegrees_gather(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const int64_t* nodes, int64_t count,
                               int outdegree_coding, int32_t* out, uint64_t* first, hipStream_t s);
 // exclusive prefix sum of int32 -> uint64 (n+1 outputs), single stream, hand-written 3-phase scan
 void launch_exclusive_scan(const int32_t* in, uint64_t* out, int64_t n, uint64_t* tmp, hipStream_t s);
 size_t scan_tmp_elems(int64_t n);
 
 // plan: block boundaries at ~equal compressed bits, then per-boundary halo (reference-chain walk)
-void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s);
+void launch_plan_boundaries(Offsets offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s);
 // (window > kMaxWindow: halo = distance to the farthest node reached, up to kMaxHaloBig, mask = all ones)
-void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first, uint32_t nblk,
+void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t n, const uint64_t* first, uint32_t nblk,
                       int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s);
 
 // plan: largest outdegree among the nodes a block decodes (its own + its halo): predicts the LDS tier it needs
-void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
+void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
                       int outdegree_coding, int window, uint32_t* maxd, hipStream_t s);
 
 // offsets index from a bare .graph (BVGraph -O / writeOffsets, BVG:2595-2609; loadSequential/loadOffline, BVG:1345-1464):
@@ -126,7 +138,7 @@ int encode_store_dev(const bvg_params& p, const uint64_t* d_adj_off, const int64
 
 // synthetic tiling (bvg_tile)
 void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
-void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s);
+void launch_tile_offsets(Offsets src, int64_t n, uint64_t src_bits, uint32_t* dst_lo, uint64_t* dst_hi, int64_t copies, hipStream_t s);   // packed output
 
 // transposition feed (bvg_transpose.hip): stable radix sort of (target, source) pairs + in-degree prefix
 size_t transpose_temp_bytes(uint64_t arcs, int64_t n);

@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void outdegree_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to,
+__global__ void outdegree_kernel(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t from, int64_t to,
                                  int coding, int32_t* out, unsigned long long* total) {
     int64_t x = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t d = 0;
@@ -344,7 +344,7 @@ __global__ void outdegree_kernel(const uint8_t* graph, uint64_t limit_byte, cons
     }
 }
 
-__global__ void outdegree_gather_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const int64_t* nodes, int64_t count,
+__global__ void outdegree_gather_kernel(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const int64_t* nodes, int64_t count,
                                         int coding, int32_t* out, uint64_t* first) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -394,7 +394,7 @@ __global__ void scan_final(const int32_t* in, int64_t n, const uint64_t* partial
 }
 
 // ---- plan ----
-__global__ void plan_boundaries_kernel(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first) {
+__global__ void plan_boundaries_kernel(Offsets offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first) {
     uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j > nb) return;
     if (j == nb) { first[j] = (uint64_t)n; return; }
@@ -405,7 +405,7 @@ __global__ void plan_boundaries_kernel(const uint64_t* offsets, int64_t n, uint6
     first[j] = (uint64_t)lo;
 }
 
-__global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first,
+__global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t n, const uint64_t* first,
                                  uint32_t nblk, int window, Codings cod, uint32_t* halo, uint64_t* mask) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nblk) return;
@@ -440,7 +440,7 @@ __global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, cons
 
 // one wavefront per block: lanes stride over the block's nodes (coalesced offsets reads); the value kept is
 // the largest "own list + the W lists before it" — what the LDS pool must hold to decode that node at all
-__global__ void plan_maxd_kernel(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo,
+__global__ void plan_maxd_kernel(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo,
                                  uint32_t nblk, int coding, int window, uint32_t* maxd) {
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= nblk) return;
@@ -509,13 +509,35 @@ __global__ void tile_graph_kernel(const uint8_t* src, uint64_t src_bits, uint8_t
     reinterpret_cast<uint64_t*>(dst)[w] = __builtin_bswap64(val);
     }
 }
-__global__ void tile_offsets_kernel(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies) {
+__device__ __forceinline__ uint64_t tiled_offset(const Offsets& src, int64_t n, uint64_t src_bits, int64_t copies, int64_t i) {
+    if (i >= n * copies) return (uint64_t)copies * src_bits;
+    const int64_t c = i / n, r = i - c * n;
+    return (uint64_t)c * src_bits + src[r];
+}
+// offsets of `copies` concatenated copies, written in packed form straight away (a tile never spans 2^32 bits per 2^kOffShift nodes
+// unless its source does)
+__global__ void tile_offsets_kernel(Offsets src, int64_t n, uint64_t src_bits, uint32_t* dst_lo, uint64_t* dst_hi, int64_t copies) {
     const int64_t tot = n * copies;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= tot; i += (int64_t)gridDim.x * blockDim.x) {
-        if (i == tot) { dst[i] = (uint64_t)copies * src_bits; continue; }
-        int64_t c = i / n, r = i - c * n;
-        dst[i] = (uint64_t)c * src_bits + src[r];
+        const uint64_t v = tiled_offset(src, n, src_bits, copies, i);
+        const uint64_t b = tiled_offset(src, n, src_bits, copies, i & ~(((int64_t)1 << kOffShift) - 1));
+        dst_lo[i] = (uint32_t)(v - b);
+        if ((i & (((int64_t)1 << kOffShift) - 1)) == 0) dst_hi[i >> kOffShift] = v;
     }
+}
+
+__global__ void pack_offsets_kernel(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = first + j;
+        const uint64_t v = src[j], b = src[j & ~(((int64_t)1 << kOffShift) - 1)];
+        if (v < b || v - b > 0xFFFFFFFFull) { atomicOr(overflow, 1u); continue; }
+        lo[x] = (uint32_t)(v - b);
+        if ((x & (((int64_t)1 << kOffShift) - 1)) == 0) hi[x >> kOffShift] = v;
+    }
+}
+
+__global__ void unpack_offsets_kernel(Offsets o, int64_t first, int64_t count, uint64_t* dst) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (int64_t)gridDim.x * blockDim.x) dst[j] = o[first + j];
 }
 
 }  // namespace
@@ -549,14 +571,14 @@ void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materi
 #undef BVG_LAUNCH
 }
 
-void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t from, int64_t to, int coding,
+void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t from, int64_t to, int coding,
                        int32_t* out, unsigned long long* total, hipStream_t s) {
     int64_t n = to - from;
     if (n <= 0) return;
     hipLaunchKernelGGL(outdegree_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, graph, limit_byte, offsets, from, to, coding, out, total);
 }
 
-void launch_outdegrees_gather(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const int64_t* nodes, int64_t count,
+void launch_outdegrees_gather(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const int64_t* nodes, int64_t count,
                               int coding, int32_t* out, uint64_t* first, hipStream_t s) {
     if (count <= 0) return;
     hipLaunchKernelGGL(outdegree_gather_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, graph, limit_byte, offsets, nodes, count, coding, out, first);
@@ -596,17 +618,17 @@ void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s)
     hipLaunchKernelGGL(reduce_acc_kernel, dim3(1), dim3(256), 0, s, acc, stripes);
 }
 
-void launch_plan_boundaries(const uint64_t* offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s) {
+void launch_plan_boundaries(Offsets offsets, int64_t n, uint64_t block_bits, uint64_t nb, uint64_t* first, hipStream_t s) {
     hipLaunchKernelGGL(plan_boundaries_kernel, dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, s, offsets, n, block_bits, nb, first);
 }
 
-void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, int64_t n, const uint64_t* first, uint32_t nblk,
+void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t n, const uint64_t* first, uint32_t nblk,
                       int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s) {
     if (!nblk) return;
     hipLaunchKernelGGL(plan_halo_kernel, dim3((nblk + 127) / 128), dim3(128), 0, s, graph, limit_byte, offsets, n, first, nblk, window, cod, halo, mask);
 }
 
-void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, const uint64_t* offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
+void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
                       int coding, int window, uint32_t* maxd, hipStream_t s) {
     if (!nblk) return;
     hipLaunchKernelGGL(plan_maxd_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, graph, limit_byte, offsets, first, halo, nblk, coding, window, maxd);
@@ -616,9 +638,17 @@ void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint
     uint64_t words = dst_bytes / 8;
     hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)std::min<uint64_t>((words + 255) / 256, 1u << 22)), dim3(256), 0, s, src, src_bits, dst, words, src_bits * (uint64_t)copies);
 }
-void launch_tile_offsets(const uint64_t* src, int64_t n, uint64_t src_bits, uint64_t* dst, int64_t copies, hipStream_t s) {
+void launch_tile_offsets(Offsets src, int64_t n, uint64_t src_bits, uint32_t* dst_lo, uint64_t* dst_hi, int64_t copies, hipStream_t s) {
     int64_t tot = n * copies + 1;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 1 << 22)), dim3(256), 0, s, src, n, src_bits, dst, copies);
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 1 << 22)), dim3(256), 0, s, src, n, src_bits, dst_lo, dst_hi, copies);
+}
+void launch_pack_offsets(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(pack_offsets_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1 << 20)), dim3(256), 0, s, src, first, count, lo, hi, overflow);
+}
+void launch_unpack_offsets(Offsets o, int64_t first, int64_t count, uint64_t* dst, hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(unpack_offsets_kernel, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 1 << 20)), dim3(256), 0, s, o, first, count, dst);
 }
 
 }  // namespace bvg

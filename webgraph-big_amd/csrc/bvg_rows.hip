@@ -27,7 +27,7 @@
 #include <type_traits>
 
 #ifndef BVG_ROWS_WAVES
-#define BVG_ROWS_WAVES 6
+#define BVG_ROWS_WAVES 5
 #endif
 #ifndef BVG_TASK_WAVES
 #define BVG_TASK_WAVES 5
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (tl[u] && q) {
                         const uint64_t e = sk_base + t_ef + q - 1u;
                         trel[u] = t_rec + a.skip_bit[e]; r[u] = reinterpret_cast<const T*>(a.skip_val)[e];
-                        if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
+                        if (!(trel[u] > t_rel && trel[u] < t_pend) || trel[u] - t_rec == 0xFFFFu) { tbad = true; cnt[u] = 0; trel[u] = 0; }
                     }
                 }
                 auto decode_tasks = [&](auto ZF) {                            // ZF: the 32-bit zeta fast path is compiled in (no test inside the loop)
@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (a.skip_mode == 2 && cntE && t && (t & (kSkipEvery - 1u)) == 0) {  // fill the skip entry of this residual
                         const uint32_t ei = efirst + (t / kSkipEvery) - 1u;                // inside the block's allotment only: a block
                         if (ei < sk_n) {                                                    // that ends in the generic kernel has none
-                            a.skip_bit[sk_base + ei] = rel - recrel; reinterpret_cast<T*>(a.skip_val)[sk_base + ei] = r;
+                            a.skip_bit[sk_base + ei] = (uint16_t)(rel - recrel < 0xFFFFu ? rel - recrel : 0xFFFFu); reinterpret_cast<T*>(a.skip_val)[sk_base + ei] = r;   // (0xFFFF: unusable, the reader fails over)
                         }
                     }
                     uint64_t val;

@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                     if (q) {
                         const uint64_t en = sk_base + t_ef + q - 1u;
                         trel = t_rec + a.skip_bit[en]; r = reinterpret_cast<const T*>(a.skip_val)[en];
-                        if (!(trel > t_rel && trel < t_pend)) lbad = true;
+                        if (!(trel > t_rel && trel < t_pend) || trel - t_rec == 0xFFFFu) lbad = true;
                     }
                     T* const tail = pool + t_dst + t0;
                     for (uint32_t i = 0; i < cnt && !lbad; i++) {
