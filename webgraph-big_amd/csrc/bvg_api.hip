@@ -58,14 +58,15 @@ struct Plan {
     uint64_t version = 0;
     // residual skip index (built by two passes of the row kernel the first time a large range is decoded)
     std::atomic<int> skip_state{0};           // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index); published with release order
-    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint16_t* d_skip_bit = nullptr; void* d_skip_val = nullptr;
+    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint16_t* d_skip_bit = nullptr; void* d_skip_val = nullptr; uint8_t* d_skip_fmt = nullptr;
     bool skip_wide = false;                   // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
     std::vector<uint64_t> h_skip_first;
     void release_skip() {
         if (d_skip_first) (void)hipFree(d_skip_first);
         if (d_skip_bit) (void)hipFree(d_skip_bit);
         if (d_skip_val) (void)hipFree(d_skip_val);
-        d_skip_first = nullptr; d_skip_bit = nullptr; d_skip_val = nullptr; skip_total = 0; skip_state.store(0); h_skip_first.clear();
+        if (d_skip_fmt) (void)hipFree(d_skip_fmt);
+        d_skip_first = nullptr; d_skip_bit = nullptr; d_skip_val = nullptr; d_skip_fmt = nullptr; skip_total = 0; skip_state.store(0); h_skip_first.clear();
     }
     void release() {
         release_skip();
@@ -124,7 +125,7 @@ struct bvg_graph {
     size_t tr_o_cum = 0, tr_o_succ = 0;             // where the last transpose left the graph's own CSR in it (bvg_symmetrize)
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     struct Pred {
-        uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[6] = {0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
+        uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
         std::vector<uint8_t> learned; uint64_t learned_version = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
     } pred;
 };
@@ -334,7 +335,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp) {
     for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + cnt[i];
     const uint64_t total = first[nblk];
     if (total == 0) { pl.skip_state.store(1, std::memory_order_release); return 0; }
-    if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint16_t) + 16) != hipSuccess ||
+    if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint16_t) + 16) != hipSuccess || hipMalloc(&pl.d_skip_fmt, nblk) != hipSuccess || hipMemset(pl.d_skip_fmt, 0, nblk) != hipSuccess ||
         hipMalloc(&pl.d_skip_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); (void)hipGetLastError(); return 0; }
     if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
     pl.skip_total = total; pl.skip_wide = build_wide;
@@ -357,6 +358,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     std::shared_ptr<Plan> plp = use_plan ? *use_plan : no_plan;                     // held for the whole call (see Shared::plans)
     if (!batch && !use_plan) { r = build_plan(g, block_bits_of(g), plp); if (r) return r; }
     const bool rows_default = (g->tun.reserved & 0xFF) == 0 && !force_slow;
+    const bool force_giant = !force_slow && getenv("BVG_GIANT") && atoi(getenv("BVG_GIANT")) == 2;   // tests: every block through the giant kernel
     if (!batch && rows_default && g->skip_mode == 0 && !plp->skip_state.load(std::memory_order_acquire) && !getenv("BVG_NOSKIP") &&
         (to - from) >= sh->p.nodes / 4 && (to - from) >= 4096) { r = build_skip(g, plp); if (r) return r; }
     const Plan& pl = *plp;
@@ -404,7 +406,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
     if (!batch && rows_default && pl.skip_total && pl.skip_wide == wide && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state.load(std::memory_order_acquire))) {
-        a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val;
+        a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val; a.skip_fmt = pl.d_skip_fmt;
     }
 #ifdef BVG_EXPERIMENTAL
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
@@ -465,6 +467,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const int nw = is_class && wg_class ? wg_class : wg_nw;
         if (nw) launch_rows_wg_decode(aa, nb, nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
     };
+    // tier 2a (bvg_giant.hip): lists / records too large for LDS, decoded by a whole workgroup each; default codings and windows <= 64
+    // (anything else, and whatever it refuses, takes the generic kernel).  BVG_GIANT=0 switches it off.
+    bool giant_ok = false;
+    {
+        const Codings& c = a.cod;
+        const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
+        giant_ok = dflt && rows_default && sh->p.window_size <= kMaxWindow && !(getenv("BVG_GIANT") && atoi(getenv("BVG_GIANT")) == 0);
+    }
     uint32_t launches = 0, slow_blocks = 0;
     bool predicted_run = false;                        // cascade outcomes of a predicted run are remembered in g->pred
     double kernel_ms = 0;
@@ -498,7 +508,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         return 0;
     };
     // ---- tier 0: every block, LDS sized for occupancy (the list pool holds one row of 64 lists + the window)
-    if (nblocks && !force_slow) {
+    if (nblocks && !force_slow && !force_giant) {
         if (stream) {                                       // list ring: power of two
             uint64_t want = (uint64_t)(avg * 72.0), cap = 2048;
             while (cap * 2 <= want && cap < (wide ? 8192u : 16384u)) cap *= 2;
@@ -569,7 +579,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             }
             if (rekey) pd.dirty = false;
             if (rekey || pd.dirty) {
-                std::vector<uint32_t> L[6];
+                std::vector<uint32_t> L[7];                                      // tier 0, four LDS classes, giants (5), the generic kernel (6)
                 uint64_t gneed = 0;
                 for (uint32_t i = 0; i < nblocks; i++) {
                     const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
@@ -579,15 +589,16 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     if (long_record) c = 5;
                     else if (need <= cap0) c = 0;
                     else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
-                    if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c == 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
-                    if (c == 5 && need > gneed) gneed = need;
+                    if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c >= 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
+                    if (c == 5 && !giant_ok) c = 6;
+                    if (c >= 5 && need > gneed) gneed = need;
                     L[c].push_back(lo + i);
                 }
                 pd.dirty = false; pd.mode = pmode;
                 if (pd.d_lists) { (void)hipFree(pd.d_lists); pd.d_lists = nullptr; }
                 HIPCHK(hipMalloc(&pd.d_lists, (size_t)nblocks * sizeof(uint32_t)));
                 size_t off = 0;
-                for (int c = 0; c < 6; c++) {
+                for (int c = 0; c < 7; c++) {
                     pd.count[c] = (uint32_t)L[c].size();
                     if (!L[c].empty()) HIPCHK(hipMemcpy(pd.d_lists + off, L[c].data(), L[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                     off += L[c].size();
@@ -596,9 +607,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             }
             // giants: global-memory pools sized to the largest list, allocated before anything is launched
             uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0;
-            if (pd.count[5]) {
-                gpool_elems = 1ull << 16; while (gpool_elems < pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(pd.count[5], getenv("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(getenv("BVG_GBATCH"))) : 1024u);
+            const uint32_t ngiant = pd.count[5] + pd.count[6];
+            if (ngiant) {
+                // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
+                gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, getenv("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(getenv("BVG_GBATCH"))) : 1024u);
                 const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
                 if (bytes > g->giant_ws_bytes) {
                     if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
@@ -610,17 +623,20 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             size_t off = 0;
             DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
             off += pd.count[0];
-            size_t offc[6]; { size_t o = 0; for (int c = 0; c < 6; c++) { offc[c] = o; o += pd.count[c]; } }
+            size_t offc[7]; { size_t o = 0; for (int c = 0; c < 7; c++) { offc[c] = o; o += pd.count[c]; } }
             const bool tier0_first = getenv("BVG_ORDER") && atoi(getenv("BVG_ORDER")) == 1;
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
-            if (pd.count[5] && gbatch) {                                       // giants first: they are the critical path
+            if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
-                for (uint32_t o2 = 0; o2 < pd.count[5]; o2 += gbatch) {
-                    ag.work_list = pd.d_lists + offc[5] + o2;
-                    launch_decode(ag, std::min<uint32_t>(gbatch, pd.count[5] - o2), wide, materialise, true, g->side[0]);
-                    launches++;
-                }
+                for (int c = 5; c <= 6; c++)
+                    for (uint32_t o2 = 0; o2 < pd.count[c]; o2 += gbatch) {
+                        ag.work_list = pd.d_lists + offc[c] + o2;
+                        const uint32_t nb = std::min<uint32_t>(gbatch, pd.count[c] - o2);
+                        if (c == 5) launch_giant_decode(ag, nb, wide, materialise, g->side[0]);
+                        else launch_decode(ag, nb, wide, materialise, true, g->side[0]);
+                        launches++;
+                    }
             }
             for (int c = 4; c >= 1; c--) {                                     // LDS size classes, largest first
                 if (!pd.count[c]) continue;
@@ -635,12 +651,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             HIPCHK(hipStreamSynchronize(g->stream));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
             kernel_ms += ms;
-            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant blocks, %.3f ms\n",
-                                             pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], ms);
+            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant + %u generic blocks, %.3f ms\n",
+                                             pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], pd.count[6], ms);
             slow_blocks = nblocks - pd.count[0];
             predicted_run = true;
-            if (pd.count[5] && !gbatch) {                                      // could not get the giant workspace: leave them to the cascade
-                std::vector<uint32_t> gl(pd.count[5]);
+            if (ngiant && !gbatch) {                                           // could not get the giant workspace: leave them to the cascade
+                std::vector<uint32_t> gl(ngiant);
                 HIPCHK(hipMemcpy(gl.data(), pd.d_lists + offc[5], gl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 r = fetch_failures(work); if (r) return r;
                 work.insert(work.end(), gl.begin(), gl.end());
@@ -659,11 +675,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         r = fetch_failures(work); if (r) return r;
         slow_blocks = (uint32_t)work.size();
         }
-    } else if (force_slow) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; slow_blocks = nblocks; }
+    } else if (force_slow || force_giant) { work.resize(nblocks); for (uint32_t i = 0; i < nblocks; i++) work[i] = batch ? 2 * i : lo + i; slow_blocks = nblocks; }
 
     // ---- tier 1: the few blocks holding a list that overflowed the small pool, re-run with a pool sized to
     //      what each block reported it needs (size classes keep as many waves resident as possible)
-    if (!work.empty() && !force_slow) {
+    if (!work.empty() && !force_slow && !force_giant) {
         std::vector<uint32_t> need(work.size());
         HIPCHK(hipMemcpy(need.data(), g->d_fail + 1 + g->fail_cap, work.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         const uint32_t max_pool = wide ? 6144 : 12288;
@@ -697,39 +713,56 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         work.swap(rest);
         if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 5; pd.dirty = true; } }
     }
-    // ---- tier 2: global-memory pools (kept in the handle), grown until every remaining block fits
-    uint64_t pool_elems = 1ull << 20;
-    while (!work.empty()) {
-        uint64_t scr_elems = pool_elems / 2;
-        uint64_t per_wg = (pool_elems + scr_elems) * esz;
-        size_t free_b = 0, total_b = 0;
-        HIPCHK(hipMemGetInfo(&free_b, &total_b));
-        uint32_t batch = (uint32_t)std::min<uint64_t>({(uint64_t)work.size(), std::max<uint64_t>(1, ((free_b + g->slow_ws_bytes) / 2) / per_wg), 1024});
-        if ((uint64_t)batch * per_wg > g->slow_ws_bytes) {
-            if (g->slow_ws) { (void)hipFree(g->slow_ws); g->slow_ws = nullptr; g->slow_ws_bytes = 0; }
-            if (hipMalloc(&g->slow_ws, (size_t)batch * per_wg) != hipSuccess) { if (d_work) (void)hipFree(d_work); return BVG_E_NOMEM; }
-            g->slow_ws_bytes = (uint64_t)batch * per_wg;
-        }
-        r = upload_work(); if (r) return r;
-        a.gpool = g->slow_ws; a.gpool_elems = pool_elems;
-        a.gscr = (char*)g->slow_ws + (size_t)batch * pool_elems * esz; a.gscr_elems = scr_elems;
-        a.lds_stage_words = 1024;
-        const size_t nwork = work.size();
-        r = timed("tier2 (global)", nwork, [&] {
-            for (size_t off = 0; off < nwork; off += batch) {
-                uint32_t nb = (uint32_t)std::min<size_t>(batch, nwork - off);
-                a.work_list = d_work + off;
-                launch_decode(a, nb, wide, materialise, true, g->stream);
-                launches++;
+    // ---- tier 2a / 2: per-workgroup areas in global memory (kept in the handle), grown until every remaining block fits.  First the
+    //      giant kernel (a workgroup per list); what it refuses (overlapping streams, contradictory counts) goes to the generic kernel.
+    auto run_global_tier = [&](bool giant, std::vector<uint32_t>& refused) -> int {
+        uint64_t pool_elems = 1ull << 20;
+        while (!work.empty()) {
+            uint64_t scr_elems = pool_elems / 2;
+            uint64_t per_wg = (pool_elems + scr_elems) * esz;
+            size_t free_b = 0, total_b = 0;
+            HIPCHK(hipMemGetInfo(&free_b, &total_b));
+            uint32_t batch = (uint32_t)std::min<uint64_t>({(uint64_t)work.size(), std::max<uint64_t>(1, ((free_b + g->slow_ws_bytes) / 2) / per_wg), 1024});
+            if ((uint64_t)batch * per_wg > g->slow_ws_bytes) {
+                if (g->slow_ws) { (void)hipFree(g->slow_ws); g->slow_ws = nullptr; g->slow_ws_bytes = 0; }
+                if (hipMalloc(&g->slow_ws, (size_t)batch * per_wg) != hipSuccess) { if (d_work) (void)hipFree(d_work); d_work = nullptr; return BVG_E_NOMEM; }
+                g->slow_ws_bytes = (uint64_t)batch * per_wg;
             }
-        });
-        if (r) return r;
-        r = fetch_failures(work); if (r) return r;
-        if (!work.empty()) {
-            if (pool_elems >= (1ull << 34)) { if (d_work) (void)hipFree(d_work); return BVG_E_NOMEM; }
-            pool_elems *= 8;
+            int r2 = upload_work(); if (r2) return r2;
+            a.gpool = g->slow_ws; a.gpool_elems = pool_elems;
+            a.gscr = (char*)g->slow_ws + (size_t)batch * pool_elems * esz; a.gscr_elems = scr_elems;
+            a.lds_stage_words = 1024;
+            const size_t nwork = work.size();
+            r2 = timed(giant ? "tier2a (giant)" : "tier2 (generic)", nwork, [&] {
+                for (size_t off = 0; off < nwork; off += batch) {
+                    uint32_t nb = (uint32_t)std::min<size_t>(batch, nwork - off);
+                    a.work_list = d_work + off;
+                    if (giant) launch_giant_decode(a, nb, wide, materialise, g->stream); else launch_decode(a, nb, wide, materialise, true, g->stream);
+                    launches++;
+                }
+            });
+            if (r2) return r2;
+            r2 = fetch_failures(work); if (r2) return r2;
+            if (giant && !work.empty()) {                                     // only "the area is too small" is worth another round
+                std::vector<uint32_t> need(work.size()), again;
+                HIPCHK(hipMemcpy(need.data(), g->d_fail + 1 + g->fail_cap, work.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                for (size_t i = 0; i < work.size(); i++) (need[i] == 0xFFFFFFF2u ? again : refused).push_back(work[i]);
+                work.swap(again);
+            }
+            if (!work.empty()) {
+                if (pool_elems >= (1ull << 34)) { if (giant) { refused.insert(refused.end(), work.begin(), work.end()); work.clear(); break; } if (d_work) (void)hipFree(d_work); d_work = nullptr; return BVG_E_NOMEM; }
+                pool_elems *= 8;
+            }
         }
+        return 0;
+    };
+    if (!work.empty() && giant_ok && !force_slow) {
+        std::vector<uint32_t> refused;
+        r = run_global_tier(true, refused); if (r) return r;
+        work.swap(refused);
+        if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 6; pd.dirty = true; } }
     }
+    { std::vector<uint32_t> none; r = run_global_tier(false, none); if (r) return r; }
     if (d_work) (void)hipFree(d_work);
 
     unsigned long long acc[24];

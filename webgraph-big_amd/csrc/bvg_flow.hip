@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
         if ((uint64_t)(e - hs) > kFlowNodes) { failed = true; fail_need = 0xFFFFFFF6u; }
 
         // residual skip index of this block
-        const bool sk_have = a.skip_first != nullptr;
+        const bool sk_have = a.skip_first != nullptr && (!a.skip_fmt || a.skip_fmt[bid] == 1);
         const uint64_t sk_base = sk_have ? a.skip_first[bid] : 0ull;
         const uint32_t sk_n = sk_have ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
         uint32_t sk_run = 0;

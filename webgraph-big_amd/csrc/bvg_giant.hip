@@ -1,0 +1,420 @@
+// bvg_giant.hip — tier 2a: blocks holding a list (or a record) too large for the LDS row kernels.
+//
+// Transposed and social graphs have lists of 10^5..10^7 successors.  The generic global-memory kernel (bvg_kernels.hip,
+// decode_kernel<SLOW>) follows the reference's iterators literally with ONE lane per list: ~1 us per successor, so a handful of
+// such lists takes longer than the rest of the graph.  Here one workgroup of 256 threads walks its block node by node and
+// every node is decoded by the whole workgroup, everything in a per-workgroup area of global memory:
+//   * the record header, the copy blocks and the intervals (BVG:1015-1058) are decoded by all threads in step from a sliding LDS
+//     window over the stream (uniform control flow; thread i mod 256 stores entry i), copy blocks in prefix form, intervals as
+//     {left, elements before};
+//   * the residuals (ResidualLongIterator, BVG:902-935) are cut at the entries of the residual skip index into tasks of
+//     <= kSkipEvery gaps, one per thread, read straight from the stream in global memory; without the index (first scan, index
+//     build) they are decoded in step like the header;
+//   * the list is put together by output POSITION as in the row kernels (bvg_rows.hip): every extra (interval, residual) finds
+//     its place by binary searches (extras below it + copied elements below it: lower bound in the referenced list, rank under
+//     the copy mask), then 256 equal tasks of consecutive positions fill in the kept elements of the referenced list
+//     (MaskedLongIterator.java:73-100) and the interval elements (LongIntervalSequenceIterator.java:71-78).
+// Streams whose three parts overlap (MergedLongIterator.java:85-89 would emit the value once), counts that contradict each other,
+// non-default codings and windows > 64 fail over to decode_kernel<SLOW>; a work area that is too small is reported as such and
+// the host retries with a larger one.
+#include "bvg_rows_common.h"
+
+namespace bvg {
+
+using namespace rows;
+
+namespace {
+
+constexpr unsigned GNT = 256;
+constexpr uint32_t kGStageWords = 2048;      // LDS window over the stream: 8 KiB
+typedef MaskPrefix<uint64_t> MP;
+
+__device__ __forceinline__ uint32_t gword_be(const uint8_t* g, uint64_t w) { return __builtin_bswap32(reinterpret_cast<const uint32_t*>(g)[w]); }
+// MSB-first windows straight from the .graph bytes (readable 16 bytes past the last record)
+__device__ __forceinline__ uint32_t gwin32(const uint8_t* g, uint64_t bit) {
+    const uint64_t w = bit >> 5; return funnel(gword_be(g, w), gword_be(g, w + 1), (uint32_t)bit & 31u);
+}
+__device__ __forceinline__ uint64_t gwin64(const uint8_t* g, uint64_t bit) {
+    const uint64_t w = bit >> 5; const uint32_t sh = (uint32_t)bit & 31u;
+    const uint32_t a = gword_be(g, w), b = gword_be(g, w + 1), c = gword_be(g, w + 2);
+    return ((uint64_t)funnel(a, b, sh) << 32) | funnel(b, c, sh);
+}
+// number of elements <= v in a sorted array
+__device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t n, uint64_t v) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (arr[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+template <typename T, bool MAT>
+__global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kGStageWords];
+    __shared__ uint64_t nd_base[kRing];
+    __shared__ uint32_t nd_d[kRing];
+    __shared__ uint32_t wg_bad;
+
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
+    const int64_t s = (int64_t)a.blk_first[bid], e = (int64_t)a.blk_first[bid + 1];
+    if (e <= a.from || s >= a.to || s >= e) return;
+    const uint32_t halo = a.blk_halo[bid];
+    const uint64_t hmask = a.blk_mask[bid];
+    const uint32_t W = (uint32_t)a.window;
+    const int64_t hs = s - (int64_t)halo;
+    const int64_t rep_lo = s > a.from ? s : a.from, rep_hi = e < a.to ? e : a.to;
+
+    T* const pool = reinterpret_cast<T*>(a.gpool) + (uint64_t)blockIdx.x * a.gpool_elems;
+    uint64_t* const scr = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.gscr) + (uint64_t)blockIdx.x * a.gscr_elems * sizeof(T));
+    const uint64_t CAP = a.gpool_elems < 0xFFFFFFF0ull ? a.gpool_elems : 0xFFFFFFF0ull;    // (positions inside the area are 32-bit)
+    const uint64_t SCR = a.gscr_elems * sizeof(T) / sizeof(uint64_t);
+    const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
+    const bool zfast = zk >= 2;
+    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
+    const bool nbz = a.node_base == 0;
+
+    for (unsigned i = tid; i < (unsigned)kRing; i += GNT) { nd_base[i] = 0; nd_d[i] = 0; }
+    if (tid == 0) wg_bad = 0;
+    __syncthreads();
+
+    // residual skip index: a giant's entry takes two 16-bit slots (its records are longer than 64 Kbit), format 2
+    const bool sk_any = a.skip_first != nullptr && !a.batch;
+    const uint64_t sk_base = sk_any ? a.skip_first[bid] : 0ull;
+    const uint32_t sk_slots = sk_any ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
+    const bool sk_use = a.skip_mode == 0 && sk_slots != 0 && a.skip_fmt && a.skip_fmt[bid] == 2;
+    const bool sk_fill = a.skip_mode == 2 && sk_any;
+    uint32_t sk_run = 0;                                       // slots of the nodes walked so far
+
+    uint64_t pool_used = 0;
+    uint64_t stg_bit0 = 0; uint32_t stg_bits = 0;
+    uint64_t chk = 0, blk_arcs = 0, blk_nodes = 0;             // chk: per thread; arcs / nodes: uniform
+    unsigned err = 0;
+    bool failed = false;
+    uint32_t fail_need = 0xFFFFFFF5u;
+    uint64_t cur = 0;                                          // bit cursor of the walk in step (uniform)
+
+    // the window covers [cur, cur + 192) bits, or reaches the end of the stream
+    auto ensure = [&]() {
+        if (cur >= stg_bit0 && (cur + 192 <= stg_bit0 + stg_bits || stg_bit0 + stg_bits >= a.padded_bytes * 8ull) && stg_bits) return;
+        __syncthreads();
+        const uint64_t b0 = (cur >> 3) & ~15ull;
+        uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
+        if (nb > kGStageWords * 4ull) nb = kGStageWords * 4ull;
+        for (uint32_t c = tid; c < (uint32_t)(nb >> 4); c += GNT) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
+            uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
+            *reinterpret_cast<uint4*>(&stage[c << 2]) = w;
+        }
+        stg_bit0 = b0 << 3; stg_bits = (uint32_t)(nb << 3);
+        __syncthreads();
+    };
+    auto rd_gamma = [&](uint64_t& v) -> bool {
+        ensure();
+        const uint32_t l = gamma64(win64<LIN>(stage, (uint32_t)(cur - stg_bit0)), v);
+        cur += l; return l != 0;
+    };
+
+    for (int64_t x = hs; x < e; x++) {
+        const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
+        if (!(x >= s || ((hmask >> hbit) & 1ull))) continue;
+        const uint64_t off_x = a.offsets[x], rec_end = a.offsets[x + 1];
+        cur = off_x;
+        uint64_t v;
+        bool bad = false;
+        // ---------------------------------------------------------------- header, in step (BVG:1003-1058)
+        if (!rd_gamma(v) || v > 0x7FFFFFFFull) { failed = true; break; }
+        const uint32_t d = (uint32_t)v;
+        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, rlen = 0, ivtot = 0;
+        uint64_t rlb = 0;
+        int64_t extra = d;
+        if (d > 0) {
+            if (W > 0) {                                                       // readReference (unary), BVG:692-703
+                ensure();
+                const uint64_t w = win64<LIN>(stage, (uint32_t)(cur - stg_bit0));
+                const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                if (lz >= 64) { failed = true; break; }
+                cur += lz + 1; v = lz;
+                if (v > W || (int64_t)v > x) { err |= ERR_REF_RANGE; v = 0; }
+                ref = (uint32_t)v;
+            }
+            if (ref > 0) {
+                rlen = nd_d[(uint32_t)(x - ref) & RM]; rlb = nd_base[(uint32_t)(x - ref) & RM];
+                if (!rd_gamma(v) || v > rec_end - (cur < rec_end ? cur : rec_end) + 1) { failed = true; break; }
+                bc = (uint32_t)v;
+                if ((uint64_t)bc + 4 > SCR) { failed = true; fail_need = 0xFFFFFFF2u; break; }
+                uint64_t tot = 0, copied = 0;
+                for (uint32_t i = 0; i < bc; i++) {                            // copy blocks, BVG:1023-1032, in prefix form
+                    if (!rd_gamma(v) || cur > rec_end) { bad = true; break; }
+                    const uint64_t b = v + (i ? 1u : 0u);
+                    tot += b; if (!(i & 1u)) copied += b;
+                    if (tot > 0xFFFFFFFFull) { bad = true; break; }
+                    if ((i & (GNT - 1)) == tid) scr[i] = MP::pack((uint32_t)tot, (uint32_t)copied);
+                }
+                if (bad || tot > rlen) { failed = true; break; }               // blocks running past the referenced list: the literal kernel decides
+                if (!(bc & 1u)) copied += rlen - tot;                          // BVG:1030
+                extra = (int64_t)d - (int64_t)copied;
+                if (extra < 0) { failed = true; break; }
+            }
+            const uint64_t ib = bc;                                            // intervals behind the blocks: left[ic], before[ic + 1], position[ic]
+            if (extra > 0 && minint != 0) {                                    // BVG:1037-1058 (always gamma)
+                if (!rd_gamma(v) || v > (rec_end - (cur < rec_end ? cur : rec_end)) / 2 + 1) { failed = true; break; }
+                ic = (uint32_t)v;
+                if (ib + 3ull * ic + 4 > SCR) { failed = true; fail_need = 0xFFFFFFF2u; break; }
+                int64_t prev = 0; uint64_t before = 0;
+                for (uint32_t i = 0; i < ic; i++) {
+                    uint64_t v1, v2;
+                    if (!rd_gamma(v1) || !rd_gamma(v2) || cur > rec_end) { bad = true; break; }
+                    const int64_t left = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
+                    const int64_t len = (int64_t)v2 + minint;
+                    prev = left + len;
+                    if ((i & (GNT - 1)) == tid) { scr[ib + i] = (uint64_t)(T)left; scr[ib + ic + i] = before; }
+                    before += (uint64_t)len; extra -= len;
+                    if (left < 0 || before > 0x7FFFFFFFull) { bad = true; break; }
+                }
+                if (tid == 0) scr[ib + 2ull * ic] = before;
+                if (bad || extra < 0) { failed = true; break; }
+                ivtot = (uint32_t)before;
+            }
+            nres = (uint32_t)extra;
+        }
+        const uint64_t* const B = scr; const uint64_t* const IL = scr + bc; const uint64_t* const IC = scr + bc + ic; uint64_t* const IP = scr + bc + 2ull * ic + 1;
+
+        // ---------------------------------------------------------------- room: the list at the bottom, the residuals parked at the top
+        if (pool_used + (uint64_t)d + nres + 1 > CAP && pool_used > 0) {
+            // keep only the lists of the last W nodes, moved to the front (oldest first: a move never lands on a list not yet moved)
+            uint64_t packed = 0;
+            for (uint32_t j = W; j >= 1; j--) {
+                const int64_t y = x - (int64_t)j;
+                if (y < hs) continue;
+                const uint64_t src = nd_base[(uint32_t)y & RM]; const uint64_t len = nd_d[(uint32_t)y & RM];
+                if (src != packed)
+                    for (uint64_t t0 = 0; t0 < len; t0 += GNT) {
+                        const uint64_t t = t0 + tid; T vv = 0;
+                        if (t < len) vv = pool[src + t];
+                        __syncthreads();
+                        if (t < len) pool[packed + t] = vv;
+                        __syncthreads();
+                    }
+                __syncthreads();
+                if (tid == 0) nd_base[(uint32_t)y & RM] = packed;
+                packed += len;
+            }
+            pool_used = packed;
+            __syncthreads();
+            if (ref > 0) rlb = nd_base[(uint32_t)(x - ref) & RM];
+        }
+        if (pool_used + (uint64_t)d + nres + 1 > CAP) { failed = true; fail_need = 0xFFFFFFF2u; break; }
+        const uint64_t base = pool_used;
+        T* const out = pool + base;
+        T* const rt = pool + (CAP - nres - 1);
+        const T* const rl = pool + rlb;
+
+        // ---------------------------------------------------------------- residuals (BVG:902-935)
+        const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) / kSkipEvery : 0u;
+        const uint32_t efirst = sk_run;
+        sk_run += 2u * cntE;
+        if (nres > 0) {
+            if (sk_use && cntE) {
+                if (sk_run > sk_slots) { failed = true; break; }               // index out of step with the stream
+                __syncthreads();
+                const uint32_t Ttot = cntE + 1u;
+                for (uint32_t p0 = 0; p0 < Ttot; p0 += GNT) {
+                    const uint32_t q = p0 + tid;
+                    if (q < Ttot) {
+                        const uint32_t t0 = q * kSkipEvery;
+                        uint32_t cnt = q == cntE ? nres - t0 : kSkipEvery;
+                        uint64_t pos = cur; T r = (T)x;
+                        if (q) {
+                            const uint64_t sl = sk_base + efirst + 2ull * (q - 1u);
+                            const uint32_t rel = (uint32_t)a.skip_bit[sl] | ((uint32_t)a.skip_bit[sl + 1] << 16);
+                            pos = off_x + rel;
+                            r = sizeof(T) == 8 ? (T)(*reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(a.skip_val) + sl * 8ull))
+                                               : (T)(reinterpret_cast<const uint32_t*>(a.skip_val)[sl]);
+                            if (!(pos > cur && pos < rec_end)) { bad = true; cnt = 0; }
+                        }
+                        for (uint32_t i = 0; i < cnt; i++) {
+                            uint32_t len = 0; uint64_t val = 0;
+                            if (zfast) { uint32_t v32; len = zeta_fast32(gwin32(a.graph, pos), zk, v32); val = v32; }
+                            if (len == 0) len = zeta64(gwin64(a.graph, pos), zk, val);
+                            if (len == 0) { bad = true; break; }
+                            pos += len;
+                            r = (t0 + i) == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
+                            rt[t0 + i] = r;
+                            if (pos > rec_end) { err |= ERR_OVERRUN; break; }
+                        }
+                        if (q == cntE && pos != rec_end && !bad) err |= ERR_MALFORMED;   // SURVEY A.6 self-check
+                    }
+                }
+            } else {
+                // in step from the sliding window; thread t mod 256 stores value t, and the index build records every kSkipEvery-th start
+                T r = (T)x;
+                for (uint32_t t = 0; t < nres; t++) {
+                    if (sk_fill && cntE && t && (t & (kSkipEvery - 1u)) == 0 && tid == 0) {
+                        const uint64_t sl = sk_base + efirst + 2ull * (t / kSkipEvery - 1u);
+                        if (sl + 1 < sk_base + sk_slots) {
+                            const uint64_t rel = cur - off_x;
+                            a.skip_bit[sl] = (uint16_t)(rel & 0xFFFFu); a.skip_bit[sl + 1] = (uint16_t)((rel >> 16) & 0xFFFFu);
+                            if (sizeof(T) == 8) *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.skip_val) + sl * 8ull) = (uint64_t)r;
+                            else reinterpret_cast<uint32_t*>(a.skip_val)[sl] = (uint32_t)r;
+                            if (rel > 0xFFFFFFFFull) bad = true;
+                        }
+                    }
+                    ensure();
+                    const uint32_t rel = (uint32_t)(cur - stg_bit0);
+                    uint32_t len = 0; uint64_t val = 0;
+                    if (zfast) { uint32_t v32; len = zeta_fast32(win32<LIN>(stage, rel), zk, v32); val = v32; }
+                    if (len == 0) len = zeta64(win64<LIN>(stage, rel), zk, val);
+                    if (len == 0) { bad = true; break; }
+                    cur += len;
+                    r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
+                    if ((t & (GNT - 1)) == tid) rt[t] = r;
+                    if (cur > rec_end) { err |= ERR_OVERRUN; break; }
+                }
+                if (cur != rec_end && !bad) err |= ERR_MALFORMED;              // SURVEY A.6 self-check
+            }
+        } else if (cur != rec_end) err |= ERR_MALFORMED;
+        if (tid == 0 && nres + 1u > 0) rt[nres] = sentinel<T>();               // guard behind the residual positions
+        if (bad) atomicOr(&wg_bad, 1u);
+        __syncthreads();
+        if (wg_bad) { failed = true; break; }
+
+        // ---------------------------------------------------------------- emission by output position (BVG:1062-1090)
+        const bool rep = x >= rep_lo && x < rep_hi;
+        uint32_t k0 = 0, k1 = 0;
+        if (rep && !MAT) {
+            const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
+            k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
+        }
+        bool zbad = false;
+        // copied elements below v: rank of its lower bound in the referenced list under the mask; an element equal to one of
+        // [v, v + len) would be emitted once by the reference's merge
+        auto copied_below = [&](T vv, uint32_t len) -> uint32_t {
+            if (!rlen) return 0u;
+            const uint32_t qq = lds_lower_bound<T>(rl, rlen, vv);
+            uint32_t qn;
+            const uint32_t t = MP::rank(B, bc, rlen, qq, qn);
+            if (qn < rlen && (T)(rl[qn] - vv) < (T)len) zbad = true;
+            return t;
+        };
+        // Z1a: one thread per interval (the residual VALUES are still in place)
+        for (uint32_t q = tid; q < ic; q += GNT) {
+            const T vv = (T)IL[q]; const uint32_t len = (uint32_t)(IC[q + 1] - IC[q]);
+            const uint32_t lb = lds_lower_bound<T>(rt, nres, vv);
+            if (lb < nres && (T)(rt[lb] - vv) < (T)len) zbad = true;           // a residual inside the interval
+            const uint64_t pe = IC[q] + lb + copied_below(vv, len);
+            if (pe + len > d) { zbad = true; IP[q] = 0; } else IP[q] = pe;
+        }
+        __syncthreads();
+        // Z1b: one thread per residual: stored (and summed) at its place, its position kept
+        for (uint32_t i0 = 0; i0 < nres; i0 += GNT) {
+            const uint32_t i = i0 + tid;
+            if (i < nres) {
+                const T vv = rt[i];
+                uint64_t pe = i;
+                if (ic) {
+                    const uint32_t j = upper_bound64(IL, ic, (uint64_t)vv);    // intervals starting at or below v
+                    if (j) { pe += IC[j]; if ((uint64_t)vv - IL[j - 1] < IC[j] - IC[j - 1]) zbad = true; }
+                }
+                pe += copied_below(vv, 1u);
+                if (pe >= d) { zbad = true; pe = 0; }
+                out[pe] = vv;
+                if (!MAT && rep) chk += mix_node<T>(k0, k1, vv, nb_lo, nbz);
+                rt[i] = (T)pe;
+            }
+        }
+        __syncthreads();
+        // Z2: 256 equal tasks of consecutive output positions
+        {
+            uint32_t S = (d + GNT - 1u) / GNT; if (S < kMinTask) S = kMinTask;
+            uint32_t p = tid * S, pstop = p + S < d ? p + S : d;
+            if (tid * (uint64_t)S >= d) { p = 0; pstop = 0; }
+            uint32_t ri = 0, rnext = kInf, ivk = ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = bc;
+            T ivleft = 0;
+            if (p < pstop) {
+                ri = lds_lower_bound<T>(rt, nres, (T)p);                       // residual positions below p
+                rnext = ri < nres ? (uint32_t)rt[ri] : kInf;
+                uint32_t ie = ivtot;
+                if (ic) {                                                      // the first interval ending behind p
+                    uint32_t lo = 0, hi = ic;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (IP[mid] + (IC[mid + 1] - IC[mid]) > p) hi = mid; else lo = mid + 1; }
+                    if (lo < ic) { ivk = lo; ivpos = (uint32_t)IP[lo]; ivlen = (uint32_t)(IC[lo + 1] - IC[lo]); ivleft = (T)IL[lo]; ie = (uint32_t)IC[lo] + (p > ivpos ? p - ivpos : 0u); }
+                }
+                const uint32_t t = p - ri - ie;                                // rank of the next copied element among the kept ones
+                if (rlen) MP::select(B, bc, rlen, t, qcur, krem, bi);          // MaskedLongIterator.java:73-100
+            }
+            const uint32_t rlast = rlen ? rlen - 1u : 0u;
+            for (; p < pstop; p++) {
+                if (p == rnext) { ri++; rnext = ri < nres ? (uint32_t)rt[ri] : kInf; continue; }   // a residual: placed by Z1b
+                const uint32_t io = p - ivpos;
+                const bool ii = io < ivlen;                                    // LongIntervalSequenceIterator.java:71-78
+                T ov;
+                if (ii) {
+                    ov = (T)(ivleft + (T)io);
+                    if (io + 1u == ivlen) {
+                        ivk++; ivpos = kInf; ivlen = 0;
+                        if (ivk < ic) { ivpos = (uint32_t)IP[ivk]; ivlen = (uint32_t)(IC[ivk + 1] - IC[ivk]); ivleft = (T)IL[ivk]; }
+                    }
+                } else {
+                    if (!rlen || qcur > rlast) { zbad = true; ov = 0; }
+                    else ov = rl[qcur];
+                    qcur++;
+                    if (--krem == 0) MP::next_block(B, bc, rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
+                }
+                out[p] = ov;
+                if (!MAT && rep) chk += mix_node<T>(k0, k1, ov, nb_lo, nbz);
+            }
+        }
+        if (zbad) atomicOr(&wg_bad, 1u);
+        __syncthreads();
+        if (wg_bad) { failed = true; break; }
+        if (tid == 0) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
+        pool_used = base + d;
+        if (rep) { blk_arcs += d; blk_nodes += 1; }
+        if (MAT && rep) {                                                       // coalesced copy-out
+            const uint64_t dst0 = a.batch ? a.cum[bid >> 1] : a.cum[x - a.from];
+            for (uint64_t t = tid; t < d; t += GNT) {
+                const T vv = out[t];
+                a.succ[dst0 + t] = (int64_t)((uint64_t)vv + a.node_base);
+            }
+            if (tid == 0 && a.outdeg && !a.batch) a.outdeg[x - a.from] = (int32_t)d;
+        }
+        __syncthreads();
+    }
+
+    if (failed) {
+        if (tid == 0) {
+            uint32_t slot = atomicAdd(a.fail_count, 1u);
+            if (slot < a.fail_cap) { a.fail_list[slot] = bid; if (a.fail_need) a.fail_need[slot] = fail_need; }
+        }
+        return;
+    }
+    if (a.skip_mode == 1 && a.skip_cnt && tid == 0) a.skip_cnt[bid] = sk_run;
+    if (a.skip_mode == 2 && a.skip_fmt && tid == 0) a.skip_fmt[bid] = 2;
+    chk = wave_sum64(chk); err = wave_or32(err);
+    if (lane == 0) {
+        unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
+        if (chk) atomicAdd(&accs[1], (unsigned long long)chk);
+        if (err) atomicOr(&accs[3], (unsigned long long)err);
+        if (tid == 0) {
+            if (blk_arcs) atomicAdd(&accs[0], (unsigned long long)blk_arcs);
+            if (blk_nodes) atomicAdd(&accs[2], (unsigned long long)blk_nodes);
+        }
+    }
+}
+
+}  // namespace
+
+// scan / materialise the blocks of the work list with one 256-thread workgroup each; a.gpool / a.gscr: per-workgroup areas as for
+// decode_kernel<SLOW>.  Default codings and windows <= kMaxWindow only (the caller checks).
+void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s) {
+    if (nblocks == 0) return;
+    dim3 grid(nblocks), block(GNT);
+    if (wide) {
+        if (materialise) hipLaunchKernelGGL((giant_kernel<uint64_t, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((giant_kernel<uint64_t, false>), grid, block, 0, s, a);
+    } else {
+        if (materialise) hipLaunchKernelGGL((giant_kernel<uint32_t, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((giant_kernel<uint32_t, false>), grid, block, 0, s, a);
+    }
+}
+
+}  // namespace bvg

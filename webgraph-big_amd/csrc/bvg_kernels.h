@@ -81,6 +81,8 @@ struct DecodeArgs {
     const uint64_t* skip_first;         // nblk+1 entry indices, or nullptr
     uint16_t* skip_bit; void* skip_val; // entries: 16-bit bit offset (a record that uses the index fits the LDS window, <= 64 Kbit) + one successor-typed value (4 or 8 bytes)
     uint32_t* skip_cnt;                 // skip_mode 1: per-block entry count out
+    uint8_t* skip_fmt;                  // per block: who filled its entries (skip_mode 2) -- 1 = row kernels (one slot per entry), 2 = the giant
+                                        // kernel (two slots per entry: 32-bit offsets); a kernel uses only entries of its own format
     uint32_t skip_mode;
 };
 
@@ -99,6 +101,10 @@ void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool
 size_t flow_scratch_bytes_per_wave(int window);
 size_t flow_lds_bytes(uint32_t ring_cap);
 void launch_flow_scan(const DecodeArgs& a, uint32_t nblocks, uint32_t waves, void* scratch, uint32_t ring_cap, hipStream_t s);
+
+// tier 2a (bvg_giant.hip): blocks with lists / records too large for LDS, one 256-thread workgroup per block, work areas as for the
+// generic kernel (a.gpool / a.gscr); default codings and windows <= kMaxWindow only
+void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 
 // sums the result stripes into stripe 0 (one workgroup)
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);

@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     // residual skip index: entries of this block (sk_n > 0: use them; skip_mode 1/2: count / fill)
     const bool sk_have = a.skip_first != nullptr && !a.batch;
     const uint64_t sk_base = sk_have ? a.skip_first[bid] : 0ull;
-    const uint32_t sk_n = sk_have ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
+    const bool sk_mine = a.skip_mode != 0 || !a.skip_fmt || a.skip_fmt[bid] == 1;   // (entries filled by the giant kernel have another layout)
+    const uint32_t sk_n = sk_have && sk_mine ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
     const bool sk_track = a.skip_mode != 0 || sk_n != 0;
     uint32_t sk_run = 0;
 
@@ -857,6 +858,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
         if (a.skip_mode == 1 && a.skip_cnt) a.skip_cnt[bid] = sk_run;
+        if (a.skip_mode == 2 && a.skip_fmt && sk_have) a.skip_fmt[bid] = 1;
         unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
         atomicAdd(&accs[0], (unsigned long long)blk_arcs);
         atomicAdd(&accs[1], (unsigned long long)blk_chk);

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
     bool failed = false;
     uint32_t fail_need = 0xFFFFFFFFu;
 
-    const bool sk_have = a.skip_first != nullptr;
+    const bool sk_have = a.skip_first != nullptr && (!a.skip_fmt || a.skip_fmt[bid] == 1);
     const uint64_t sk_base = sk_have ? a.skip_first[bid] : 0ull;
     const uint32_t sk_n = sk_have ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
     uint32_t sk_run = 0;
