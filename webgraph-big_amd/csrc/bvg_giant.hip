@@ -39,6 +39,12 @@ __device__ __forceinline__ uint64_t gwin64(const uint8_t* g, uint64_t bit) {
     const uint32_t a = gword_be(g, w), b = gword_be(g, w + 1), c = gword_be(g, w + 2);
     return ((uint64_t)funnel(a, b, sh) << 32) | funnel(b, c, sh);
 }
+// a value every lane holds identically, moved to scalar registers: what is computed from it runs on the scalar unit
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+// leading zeros of a 64-bit value held in scalar registers (opaque to the optimiser, which would otherwise turn `lz < 32` into a
+// 64-bit comparison: a VECTOR instruction whose result the scalar loop has to wait for); 0xFFFFFFFF for 0
+__device__ __forceinline__ uint32_t sclz64(uint64_t w) { uint32_t r; asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(w)); return r; }
 // number of elements <= v in a sorted array
 __device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t n, uint64_t v) {
     uint32_t lo = 0, hi = n;
@@ -46,12 +52,25 @@ __device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t 
     return lo;
 }
 
+#ifdef BVG_PROF
+#define GP_T(i) do { gp_t[i] = clock64(); } while (0)
+#define GP_REPORT() do { if (tid == 0 && d > 100000u && (a.dbg & 512u)) printf("[giant] node %lld d %u ref %u bc %u ic %u nres %u | Kcycles: header %lld room %lld residuals %lld Z1a %lld Z1b %lld Z2 %lld\n", (long long)x, d, ref, bc, ic, nres, \
+    (long long)(gp_t[1] - gp_t[0]) >> 10, (long long)(gp_t[2] - gp_t[1]) >> 10, (long long)(gp_t[3] - gp_t[2]) >> 10, (long long)(gp_t[4] - gp_t[3]) >> 10, (long long)(gp_t[5] - gp_t[4]) >> 10, (long long)(gp_t[6] - gp_t[5]) >> 10); } while (0)
+#else
+#define GP_T(i) do {} while (0)
+#define GP_REPORT() do {} while (0)
+#endif
+
 template <typename T, bool MAT>
 __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
+#ifdef BVG_PROF
+    long long gp_t[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     __shared__ __attribute__((aligned(16))) uint32_t stage[kGStageWords];
     __shared__ uint64_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
     __shared__ uint32_t wg_bad;
+    __shared__ uint32_t hd[12];               // wavefront 0's header parse, handed to the others
 
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
@@ -92,92 +111,138 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
     uint32_t fail_need = 0xFFFFFFF5u;
     uint64_t cur = 0;                                          // bit cursor of the walk in step (uniform)
 
-    // the window covers [cur, cur + 192) bits, or reaches the end of the stream
-    auto ensure = [&]() {
-        if (cur >= stg_bit0 && (cur + 192 <= stg_bit0 + stg_bits || stg_bit0 + stg_bits >= a.padded_bytes * 8ull) && stg_bits) return;
-        __syncthreads();
-        const uint64_t b0 = (cur >> 3) & ~15ull;
-        uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
-        if (nb > kGStageWords * 4ull) nb = kGStageWords * 4ull;
-        for (uint32_t c = tid; c < (uint32_t)(nb >> 4); c += GNT) {
-            const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
-            uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
-            *reinterpret_cast<uint4*>(&stage[c << 2]) = w;
+    // The walk in step is WAVEFRONT 0's alone (the scalar unit is shared by the four SIMDs of a CU: four wavefronts walking in step
+    // would take turns on it); the others wait at the next barrier.  It reads from a 128-bit register buffer (hi: the next 64 bits of the stream, always valid), refilled 64 bits at a
+    // time from the LDS window: the LDS round trip is off the per-code dependency chain (a code costs ~100 cycles instead of ~600).
+    uint64_t hi = 0, lo = 0; uint32_t avail = 0, widx = 0, stg_words = 0;
+    auto seek = [&](uint64_t pos) {                            // (re)position at bit `pos`; restages the window when pos + 192 bits are not in it
+        if (!(stg_bits && pos >= stg_bit0 && (pos + 192 <= stg_bit0 + stg_bits || stg_bit0 + stg_bits >= a.padded_bytes * 8ull))) {
+            wave_sync();
+            const uint64_t b0 = (pos >> 3) & ~15ull;
+            uint64_t nb = a.padded_bytes > b0 ? a.padded_bytes - b0 : 0;
+            if (nb > kGStageWords * 4ull) nb = kGStageWords * 4ull;
+            for (uint32_t c = lane; c < (uint32_t)(nb >> 4); c += 64u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
+                uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
+                *reinterpret_cast<uint4*>(&stage[c << 2]) = w;
+            }
+            stg_bit0 = uni64(b0 << 3); stg_bits = uni32((uint32_t)(nb << 3)); stg_words = uni32((uint32_t)(nb >> 2));
+            wave_sync();
         }
-        stg_bit0 = b0 << 3; stg_bits = (uint32_t)(nb << 3);
-        __syncthreads();
+        const uint32_t rel = (uint32_t)(pos - stg_bit0), wi = rel >> 5, sh = rel & 31u;
+        const uint32_t m = kGStageWords - 1;                   // (indices past the staged words read stale LDS: never past a record's end)
+        hi = uni64(((uint64_t)stage[wi & m] << 32) | stage[(wi + 1) & m]); lo = uni64(((uint64_t)stage[(wi + 2) & m] << 32) | stage[(wi + 3) & m]);
+        if (sh) { hi = (hi << sh) | (lo >> (64u - sh)); lo <<= sh; }
+        avail = 128u - sh; widx = wi + 4; cur = pos;
     };
-    auto rd_gamma = [&](uint64_t& v) -> bool {
-        ensure();
-        const uint32_t l = gamma64(win64<LIN>(stage, (uint32_t)(cur - stg_bit0)), v);
-        cur += l; return l != 0;
+    auto consume = [&](uint32_t n) {                            // 1 <= n <= 64
+        if (n < 64u) { hi = (hi << n) | (lo >> (64u - n)); lo <<= n; } else { hi = lo; lo = 0; }
+        avail -= n; cur += n;
+        if (avail < 64u) {
+            if (widx + 2u > stg_words) { seek(cur); return; }
+            const uint64_t w = uni64(((uint64_t)stage[widx] << 32) | stage[widx + 1]); widx += 2;
+            if (avail) { hi |= w >> avail; lo = w << (64u - avail); } else { hi = w; lo = 0; }
+            avail += 64u;
+        }
     };
+    auto rd_gamma = [&](uint64_t& v) -> bool {                  // gamma of a value < 2^31, all on the scalar unit
+        const uint32_t lz = sclz64(hi);
+        if (lz > 31u) return false;
+        const uint32_t l = 2u * lz + 1u;
+        v = (hi >> (64u - l)) - 1u;
+        consume(l);
+        return true;
+    };
+    // What the walk in step decodes is collected 64 entries at a time in registers (entry i in lane i mod 64) and stored by one wavefront in one coalesced instruction: a store per entry would put a vector comparison and an
+    // exec-mask change on every iteration of the scalar loop.
+    const uint32_t wv = uni32(tid >> 6);
+    uint32_t st_a = 0, st_b = 0, st_c = 0;
+    auto put = [&](uint32_t i, uint32_t a32, uint32_t b32, uint32_t c32) {
+        const bool mine = lane == (i & 63u);                  // a comparison and a select per value: vector work beside the scalar chain, nothing feeds back
+        st_a = mine ? a32 : st_a; st_b = mine ? b32 : st_b; st_c = mine ? c32 : st_c;
+    };
+    // true for the lanes that store now: entry i was the last of its group of 64 (or the last of all)
+    auto group_full = [&](uint32_t i, uint32_t n) -> bool { return (i & 63u) == 63u || i + 1u == n; };   // scalar: the 64 entries are stored now
 
     for (int64_t x = hs; x < e; x++) {
         const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
         if (!(x >= s || ((hmask >> hbit) & 1ull))) continue;
-        const uint64_t off_x = a.offsets[x], rec_end = a.offsets[x + 1];
-        cur = off_x;
+        const uint64_t off_x = uni64(a.offsets[x]), rec_end = uni64(a.offsets[x + 1]);
         uint64_t v;
         bool bad = false;
-        // ---------------------------------------------------------------- header, in step (BVG:1003-1058)
-        if (!rd_gamma(v) || v > 0x7FFFFFFFull) { failed = true; break; }
-        const uint32_t d = (uint32_t)v;
-        uint32_t ref = 0, bc = 0, ic = 0, nres = 0, rlen = 0, ivtot = 0;
+        GP_T(0);
+        // ---------------------------------------------------------------- header, wavefront 0 in step (BVG:1003-1058)
+        uint32_t d = 0, ref = 0, bc = 0, ic = 0, nres = 0, rlen = 0, ivtot = 0;
         uint64_t rlb = 0;
-        int64_t extra = d;
-        if (d > 0) {
-            if (W > 0) {                                                       // readReference (unary), BVG:692-703
-                ensure();
-                const uint64_t w = win64<LIN>(stage, (uint32_t)(cur - stg_bit0));
-                const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
-                if (lz >= 64) { failed = true; break; }
-                cur += lz + 1; v = lz;
-                if (v > W || (int64_t)v > x) { err |= ERR_REF_RANGE; v = 0; }
-                ref = (uint32_t)v;
-            }
-            if (ref > 0) {
-                rlen = nd_d[(uint32_t)(x - ref) & RM]; rlb = nd_base[(uint32_t)(x - ref) & RM];
-                if (!rd_gamma(v) || v > rec_end - (cur < rec_end ? cur : rec_end) + 1) { failed = true; break; }
-                bc = (uint32_t)v;
-                if ((uint64_t)bc + 4 > SCR) { failed = true; fail_need = 0xFFFFFFF2u; break; }
-                uint64_t tot = 0, copied = 0;
-                for (uint32_t i = 0; i < bc; i++) {                            // copy blocks, BVG:1023-1032, in prefix form
-                    if (!rd_gamma(v) || cur > rec_end) { bad = true; break; }
-                    const uint64_t b = v + (i ? 1u : 0u);
-                    tot += b; if (!(i & 1u)) copied += b;
-                    if (tot > 0xFFFFFFFFull) { bad = true; break; }
-                    if ((i & (GNT - 1)) == tid) scr[i] = MP::pack((uint32_t)tot, (uint32_t)copied);
+        if (wv == 0) {
+            uint32_t hfail = 0;
+            do {
+                seek(off_x);
+                if (!rd_gamma(v) || v > 0x7FFFFFFFull) { hfail = 0xFFFFFFF5u; break; }
+                d = (uint32_t)v;
+                int64_t extra = d;
+                if (d == 0) break;
+                if (W > 0) {                                                   // readReference (unary), BVG:692-703
+                    const uint32_t lz = sclz64(hi);
+                    if (lz >= 63u) { hfail = 0xFFFFFFF5u; break; }
+                    consume(lz + 1); v = lz;
+                    if (v > W || (int64_t)v > x) { err |= ERR_REF_RANGE; v = 0; }
+                    ref = (uint32_t)v;
                 }
-                if (bad || tot > rlen) { failed = true; break; }               // blocks running past the referenced list: the literal kernel decides
-                if (!(bc & 1u)) copied += rlen - tot;                          // BVG:1030
-                extra = (int64_t)d - (int64_t)copied;
-                if (extra < 0) { failed = true; break; }
-            }
-            const uint64_t ib = bc;                                            // intervals behind the blocks: left[ic], before[ic + 1], position[ic]
-            if (extra > 0 && minint != 0) {                                    // BVG:1037-1058 (always gamma)
-                if (!rd_gamma(v) || v > (rec_end - (cur < rec_end ? cur : rec_end)) / 2 + 1) { failed = true; break; }
-                ic = (uint32_t)v;
-                if (ib + 3ull * ic + 4 > SCR) { failed = true; fail_need = 0xFFFFFFF2u; break; }
-                int64_t prev = 0; uint64_t before = 0;
-                for (uint32_t i = 0; i < ic; i++) {
-                    uint64_t v1, v2;
-                    if (!rd_gamma(v1) || !rd_gamma(v2) || cur > rec_end) { bad = true; break; }
-                    const int64_t left = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
-                    const int64_t len = (int64_t)v2 + minint;
-                    prev = left + len;
-                    if ((i & (GNT - 1)) == tid) { scr[ib + i] = (uint64_t)(T)left; scr[ib + ic + i] = before; }
-                    before += (uint64_t)len; extra -= len;
-                    if (left < 0 || before > 0x7FFFFFFFull) { bad = true; break; }
+                if (ref > 0) {
+                    rlen = nd_d[(uint32_t)(x - ref) & RM];
+                    if (!rd_gamma(v) || v > rec_end - (cur < rec_end ? cur : rec_end) + 1) { hfail = 0xFFFFFFF5u; break; }
+                    bc = (uint32_t)v;
+                    if ((uint64_t)bc + 4 > SCR) { hfail = 0xFFFFFFF2u; break; }
+                    uint64_t tot = 0, copied = 0;
+                    // (the loop is bounded by the count, which the record's length bounds: running off the record's end is checked behind
+                    // it, so that the loop-carried chain stays on the scalar unit -- 64-bit comparisons are vector operations)
+                    for (uint32_t i = 0; i < bc; i++) {                        // copy blocks, BVG:1023-1032, in prefix form
+                        if (!rd_gamma(v)) { bad = true; break; }
+                        const uint64_t b = v + (i ? 1u : 0u);
+                        tot += b; if (!(i & 1u)) copied += b;
+                        put(i, (uint32_t)tot, (uint32_t)copied, 0u);
+                        if (group_full(i, bc) && lane <= (i & 63u)) scr[(i & ~63u) + lane] = MP::pack(st_a, st_b);
+                    }
+                    if (bad || cur > rec_end || tot > rlen) { hfail = 0xFFFFFFF5u; break; }   // blocks running past the referenced list: the literal kernel decides
+                    if (!(bc & 1u)) copied += rlen - tot;                      // BVG:1030
+                    extra = (int64_t)d - (int64_t)copied;
+                    if (extra < 0) { hfail = 0xFFFFFFF5u; break; }
                 }
-                if (tid == 0) scr[ib + 2ull * ic] = before;
-                if (bad || extra < 0) { failed = true; break; }
-                ivtot = (uint32_t)before;
-            }
-            nres = (uint32_t)extra;
+                const uint64_t ib = bc;                                        // intervals behind the blocks: left[ic], before[ic + 1], position[ic]
+                if (extra > 0 && minint != 0) {                                // BVG:1037-1058 (always gamma)
+                    if (!rd_gamma(v) || v > (rec_end - (cur < rec_end ? cur : rec_end)) / 2 + 1) { hfail = 0xFFFFFFF5u; break; }
+                    ic = (uint32_t)v;
+                    if (ib + 3ull * ic + 4 > SCR) { hfail = 0xFFFFFFF2u; break; }
+                    int64_t prev = 0, left0 = 0; uint64_t before = 0;
+                    for (uint32_t i = 0; i < ic; i++) {
+                        uint64_t v1, v2;
+                        if (!rd_gamma(v1) || !rd_gamma(v2)) { bad = true; break; }
+                        const int64_t left = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
+                        if (i == 0) left0 = left;
+                        const int64_t len = (int64_t)v2 + minint;
+                        prev = left + len;
+                        put(i, (uint32_t)left, (uint32_t)((uint64_t)left >> 32), (uint32_t)before);
+                        if (group_full(i, ic) && lane <= (i & 63u)) { const uint32_t j = (i & ~63u) + lane; scr[ib + j] = (uint64_t)(T)(((uint64_t)st_b << 32) | st_a); scr[ib + ic + j] = st_c; }
+                        before += (uint64_t)len;
+                    }
+                    extra -= (int64_t)before;
+                    if (lane == 0) scr[ib + 2ull * ic] = before;
+                    if (bad || cur > rec_end || left0 < 0 || before > 0x7FFFFFFFull || extra < 0) { hfail = 0xFFFFFFF5u; break; }
+                    ivtot = (uint32_t)before;
+                }
+                nres = (uint32_t)extra;
+            } while (0);
+            if (lane == 0) { hd[0] = d; hd[1] = ref; hd[2] = bc; hd[3] = ic; hd[4] = nres; hd[5] = ivtot; hd[6] = hfail; hd[7] = (uint32_t)cur; hd[8] = (uint32_t)(cur >> 32); }
         }
+        __syncthreads();
+        d = hd[0]; ref = hd[1]; bc = hd[2]; ic = hd[3]; nres = hd[4]; ivtot = hd[5];
+        if (hd[6]) { failed = true; fail_need = hd[6]; break; }
+        if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];                    // where the residuals start
+        if (ref > 0) { rlen = nd_d[(uint32_t)(x - ref) & RM]; rlb = nd_base[(uint32_t)(x - ref) & RM]; }
         const uint64_t* const B = scr; const uint64_t* const IL = scr + bc; const uint64_t* const IC = scr + bc + ic; uint64_t* const IP = scr + bc + 2ull * ic + 1;
 
+        GP_T(1);
         // ---------------------------------------------------------------- room: the list at the bottom, the residuals parked at the top
         if (pool_used + (uint64_t)d + nres + 1 > CAP && pool_used > 0) {
             // keep only the lists of the last W nodes, moved to the front (oldest first: a move never lands on a list not yet moved)
@@ -208,6 +273,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         T* const rt = pool + (CAP - nres - 1);
         const T* const rl = pool + rlb;
 
+        GP_T(2);
         // ---------------------------------------------------------------- residuals (BVG:902-935)
         const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) / kSkipEvery : 0u;
         const uint32_t efirst = sk_run;
@@ -244,11 +310,11 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                         if (q == cntE && pos != rec_end && !bad) err |= ERR_MALFORMED;   // SURVEY A.6 self-check
                     }
                 }
-            } else {
-                // in step from the sliding window; thread t mod 256 stores value t, and the index build records every kSkipEvery-th start
+            } else if (wv == 0) {
+                // wavefront 0 in step from the sliding window (64 values stored at a time); the index build records every kSkipEvery-th start
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
-                    if (sk_fill && cntE && t && (t & (kSkipEvery - 1u)) == 0 && tid == 0) {
+                    if (sk_fill && cntE && t && (t & (kSkipEvery - 1u)) == 0 && lane == 0) {
                         const uint64_t sl = sk_base + efirst + 2ull * (t / kSkipEvery - 1u);
                         if (sl + 1 < sk_base + sk_slots) {
                             const uint64_t rel = cur - off_x;
@@ -258,25 +324,25 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                             if (rel > 0xFFFFFFFFull) bad = true;
                         }
                     }
-                    ensure();
-                    const uint32_t rel = (uint32_t)(cur - stg_bit0);
                     uint32_t len = 0; uint64_t val = 0;
-                    if (zfast) { uint32_t v32; len = zeta_fast32(win32<LIN>(stage, rel), zk, v32); val = v32; }
-                    if (len == 0) len = zeta64(win64<LIN>(stage, rel), zk, val);
+                    if (zfast) { uint32_t v32; len = zeta_fast32((uint32_t)(hi >> 32), zk, v32); val = v32; }
+                    if (len == 0) len = zeta64(hi, zk, val);
                     if (len == 0) { bad = true; break; }
-                    cur += len;
+                    consume(len);
                     r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
-                    if ((t & (GNT - 1)) == tid) rt[t] = r;
-                    if (cur > rec_end) { err |= ERR_OVERRUN; break; }
+                    put(t, (uint32_t)r, (uint32_t)((uint64_t)r >> 32), 0u);
+                    if (group_full(t, nres) && lane <= (t & 63u)) rt[(t & ~63u) + lane] = (T)(((uint64_t)st_b << 32) | st_a);
                 }
-                if (cur != rec_end && !bad) err |= ERR_MALFORMED;              // SURVEY A.6 self-check
+                if (cur > rec_end) err |= ERR_OVERRUN;
+                else if (cur != rec_end && !bad) err |= ERR_MALFORMED;         // SURVEY A.6 self-check
             }
-        } else if (cur != rec_end) err |= ERR_MALFORMED;
+        } else if (wv == 0 && cur != rec_end) err |= ERR_MALFORMED;
         if (tid == 0 && nres + 1u > 0) rt[nres] = sentinel<T>();               // guard behind the residual positions
         if (bad) atomicOr(&wg_bad, 1u);
         __syncthreads();
         if (wg_bad) { failed = true; break; }
 
+        GP_T(3);
         // ---------------------------------------------------------------- emission by output position (BVG:1062-1090)
         const bool rep = x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
@@ -304,6 +370,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
             if (pe + len > d) { zbad = true; IP[q] = 0; } else IP[q] = pe;
         }
         __syncthreads();
+        GP_T(4);
         // Z1b: one thread per residual: stored (and summed) at its place, its position kept
         for (uint32_t i0 = 0; i0 < nres; i0 += GNT) {
             const uint32_t i = i0 + tid;
@@ -322,6 +389,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
             }
         }
         __syncthreads();
+        GP_T(5);
         // Z2: 256 equal tasks of consecutive output positions
         {
             uint32_t S = (d + GNT - 1u) / GNT; if (S < kMinTask) S = kMinTask;
@@ -365,6 +433,8 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         }
         if (zbad) atomicOr(&wg_bad, 1u);
         __syncthreads();
+        GP_T(6);
+        GP_REPORT();
         if (wg_bad) { failed = true; break; }
         if (tid == 0) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
         pool_used = base + d;
