@@ -2,17 +2,17 @@
 //
 // Transposed and social graphs have lists of 10^5..10^7 successors.  The generic global-memory kernel (bvg_kernels.hip,
 // decode_kernel<SLOW>) follows the reference's iterators literally with ONE lane per list: ~1 us per successor, so a handful of
-// such lists takes longer than the rest of the graph.  Here one workgroup of 256 threads walks its block node by node and
+// such lists takes longer than the rest of the graph.  Here one workgroup of 1024 threads walks its block node by node and
 // every node is decoded by the whole workgroup, everything in a per-workgroup area of global memory:
-//   * the record header, the copy blocks and the intervals (BVG:1015-1058) are decoded by all threads in step from a sliding LDS
-//     window over the stream (uniform control flow; thread i mod 256 stores entry i), copy blocks in prefix form, intervals as
-//     {left, elements before};
+//   * the record header, the copy blocks and the intervals (BVG:1015-1058) are decoded by wavefront 0 in step, on the scalar unit,
+//     from a register bit buffer over a sliding LDS window of the stream (64 entries stored per instruction), copy blocks in
+//     prefix form, intervals as {left, elements before};
 //   * the residuals (ResidualLongIterator, BVG:902-935) are cut at the entries of the residual skip index into tasks of
 //     <= kSkipEvery gaps, one per thread, read straight from the stream in global memory; without the index (first scan, index
-//     build) they are decoded in step like the header;
+//     build) wavefront 0 decodes them in step like the header;
 //   * the list is put together by output POSITION as in the row kernels (bvg_rows.hip): every extra (interval, residual) finds
 //     its place by binary searches (extras below it + copied elements below it: lower bound in the referenced list, rank under
-//     the copy mask), then 256 equal tasks of consecutive positions fill in the kept elements of the referenced list
+//     the copy mask), then 1024 equal tasks of consecutive positions fill in the kept elements of the referenced list
 //     (MaskedLongIterator.java:73-100) and the interval elements (LongIntervalSequenceIterator.java:71-78).
 // Streams whose three parts overlap (MergedLongIterator.java:85-89 would emit the value once), counts that contradict each other,
 // non-default codings and windows > 64 fail over to decode_kernel<SLOW>; a work area that is too small is reported as such and
@@ -25,7 +25,7 @@ using namespace rows;
 
 namespace {
 
-constexpr unsigned GNT = 256;
+constexpr unsigned GNT = 1024;               // threads per workgroup: the phases that walk global memory are latency-bound, 16 wavefronts hide 4x what 4 do
 constexpr uint32_t kGStageWords = 2048;      // LDS window over the stream: 8 KiB
 typedef MaskPrefix<uint64_t> MP;
 
@@ -45,6 +45,14 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32(
 // leading zeros of a 64-bit value held in scalar registers (opaque to the optimiser, which would otherwise turn `lz < 32` into a
 // 64-bit comparison: a VECTOR instruction whose result the scalar loop has to wait for); 0xFFFFFFFF for 0
 __device__ __forceinline__ uint32_t sclz64(uint64_t w) { uint32_t r; asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(w)); return r; }
+// first index in [from, n) at which a monotone predicate turns true (n if never): doubling steps from `from`, then bisection
+template <typename F> __device__ __forceinline__ uint32_t gallop_first(uint32_t from, uint32_t n, F pred) {
+    uint32_t b = from, st = 1;
+    while (b + st <= n && !pred(b + st - 1u)) { b += st; st <<= 1; }
+    uint32_t lo = b, hi = b + st - 1u < n ? b + st - 1u : n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (!pred(mid)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 // number of elements <= v in a sorted array
 __device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t n, uint64_t v) {
     uint32_t lo = 0, hi = n;
@@ -371,17 +379,34 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         }
         __syncthreads();
         GP_T(4);
-        // Z1b: one thread per residual: stored (and summed) at its place, its position kept
-        for (uint32_t i0 = 0; i0 < nres; i0 += GNT) {
-            const uint32_t i = i0 + tid;
-            if (i < nres) {
+        // Z1b: the residuals in runs of consecutive ones: their places rise with them, so the three searches
+        // (intervals at or below the value, its lower bound in the referenced list, the copy block of that position) gallop on from
+        // where the residual before ended instead of starting over -- a few probes next to each other instead of ~20 far apart
+        {
+            // a wavefront takes a run of consecutive residuals, its lanes every 64th of them: coalesced loads and stores, no lane reads a
+            // line it has just written, and a lane's next value is only 64 residuals on
+            constexpr uint32_t NWV = GNT / 64u;
+            const uint32_t R = ((nres + NWV - 1u) / NWV + 63u) & ~63u;
+            const uint64_t b0 = (uint64_t)wv * R;
+            const uint32_t i0 = b0 < nres ? (uint32_t)b0 : nres, i1 = (uint64_t)i0 + R < nres ? i0 + R : nres;
+            uint32_t j = 0, qq = 0, bh = 0;                                     // intervals with left <= v; lower bound in rl; first block ending behind it
+            for (uint32_t i = i0 + lane; i < i1; i += 64u) {
                 const T vv = rt[i];
                 uint64_t pe = i;
                 if (ic) {
-                    const uint32_t j = upper_bound64(IL, ic, (uint64_t)vv);    // intervals starting at or below v
-                    if (j) { pe += IC[j]; if ((uint64_t)vv - IL[j - 1] < IC[j] - IC[j - 1]) zbad = true; }
+                    j = gallop_first(j, ic, [&](uint32_t m) { return IL[m] > (uint64_t)vv; });
+                    if (j) { const uint64_t cj = IC[j]; pe += cj; if ((uint64_t)vv - IL[j - 1] < cj - IC[j - 1]) zbad = true; }
                 }
-                pe += copied_below(vv, 1u);
+                if (rlen) {
+                    qq = gallop_first(qq, rlen, [&](uint32_t m) { return !(rl[m] < vv); });
+                    bh = gallop_first(bh, bc, [&](uint32_t m) { return MP::pos(B[m]) > qq; });
+                    const uint64_t prev = bh ? B[bh - 1] : 0ull;
+                    const bool keepb = bh < bc ? !(bh & 1u) : !(bc & 1u);       // behind the last block: kept iff their number is even
+                    uint32_t qn;
+                    if (keepb) { qn = qq; pe += MP::kept(prev) + (qq - MP::pos(prev)); }
+                    else { qn = bh < bc ? MP::pos(B[bh]) : rlen; pe += MP::kept(prev); }
+                    if (qn < rlen && rl[qn] == vv) zbad = true;                 // a copied element equal to the residual
+                }
                 if (pe >= d) { zbad = true; pe = 0; }
                 out[pe] = vv;
                 if (!MAT && rep) chk += mix_node<T>(k0, k1, vv, nb_lo, nbz);
@@ -390,7 +415,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         }
         __syncthreads();
         GP_T(5);
-        // Z2: 256 equal tasks of consecutive output positions
+        // Z2: 1024 equal tasks of consecutive output positions
         {
             uint32_t S = (d + GNT - 1u) / GNT; if (S < kMinTask) S = kMinTask;
             uint32_t p = tid * S, pstop = p + S < d ? p + S : d;
@@ -473,7 +498,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
 
 }  // namespace
 
-// scan / materialise the blocks of the work list with one 256-thread workgroup each; a.gpool / a.gscr: per-workgroup areas as for
+// scan / materialise the blocks of the work list with one 1024-thread workgroup each; a.gpool / a.gscr: per-workgroup areas as for
 // decode_kernel<SLOW>.  Default codings and windows <= kMaxWindow only (the caller checks).
 void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s) {
     if (nblocks == 0) return;

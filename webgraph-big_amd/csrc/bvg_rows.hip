@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCR)); k = kb < k ? kb : k; }
         if (k == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }        // one node's copy blocks exceed the scratch area
         sb = bincl - bc;
-        const uint32_t btot = lane_get(bincl, k - 1);
+        uint32_t btot = lane_get(bincl, k - 1);
         // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
         if (parse && lane < k) {
             if (ref > 0) {
@@ -258,7 +258,13 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         }
         const uint32_t iw = lane < k ? 2 * ic : 0u;
         const uint32_t iincl = wave_incl_scan32(iw > SCR ? SCR + 1 : iw);
-        { const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR)); k = ki < k ? ki : k; }
+        // the copy blocks of the row may have taken the whole area (interval-rich lists: transposed graphs): halve the row until the
+        // first node's intervals fit behind the blocks of the nodes that stay
+        for (;;) {
+            const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR));
+            if (ki != 0 || k <= 1) { k = ki < k ? ki : k; break; }
+            k = (k + 1u) >> 1; btot = lane_get(bincl, k - 1);
+        }
         if (k == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }        // one node's intervals exceed the scratch area
         ib = btot + iincl - iw;
         // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals

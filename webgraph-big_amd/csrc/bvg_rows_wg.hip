@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
             { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCR)); k = kb < k ? kb : k; }
             if (k == 0) { kfail = 0xFFFFFFF3u; k = 1; }                       // one node's copy blocks exceed the scratch area
             sb = bincl - bc;
-            const uint32_t btot = lane_get(bincl, k - 1);
+            uint32_t btot = lane_get(bincl, k - 1);
             if (parse0 && lane < k && !kfail) {
                 if (ref > 0) {                                                // copy blocks, BVG:1023-1032
                     int64_t copied = 0, tot = 0;
@@ -202,7 +202,11 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
             }
             const uint32_t iw = lane < k ? 2 * ic : 0u;
             const uint32_t iincl = wave_incl_scan32(iw > SCR ? SCR + 1 : iw);
-            { const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR)); k = ki < k ? ki : k; }
+            for (;;) {                                                        // (see bvg_rows.hip: the blocks may have taken the whole area)
+                const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR));
+                if (ki != 0 || k <= 1) { k = ki < k ? ki : k; break; }
+                k = (k + 1u) >> 1; btot = lane_get(bincl, k - 1);
+            }
             if (k == 0) { kfail = 0xFFFFFFF4u; k = 1; }                       // one node's intervals exceed the scratch area
             ib = btot + iincl - iw;
             if (parse0 && lane < k && !kfail) {
