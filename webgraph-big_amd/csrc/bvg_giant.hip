@@ -27,6 +27,7 @@ namespace {
 
 constexpr unsigned GNT = 1024;               // threads per workgroup: the phases that walk global memory are latency-bound, 16 wavefronts hide 4x what 4 do
 constexpr uint32_t kGStageWords = 2048;      // LDS window over the stream: 8 KiB
+constexpr uint32_t kHdrMin = 48;             // copy-block / interval sections this long get index entries (one per kSkipEvery codes)
 typedef MaskPrefix<uint64_t> MP;
 
 __device__ __forceinline__ uint32_t gword_be(const uint8_t* g, uint64_t w) { return __builtin_bswap32(reinterpret_cast<const uint32_t*>(g)[w]); }
@@ -110,6 +111,8 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
     const bool sk_use = a.skip_mode == 0 && sk_slots != 0 && a.skip_fmt && a.skip_fmt[bid] == 2;
     const bool sk_fill = a.skip_mode == 2 && sk_any;
     uint32_t sk_run = 0;                                       // slots of the nodes walked so far
+    auto rd32 = [&](uint64_t sl) -> uint32_t { return (uint32_t)a.skip_bit[sl] | ((uint32_t)a.skip_bit[sl + 1] << 16); };
+    auto wr32 = [&](uint64_t sl, uint32_t val) { a.skip_bit[sl] = (uint16_t)(val & 0xFFFFu); a.skip_bit[sl + 1] = (uint16_t)(val >> 16); };
 
     uint64_t pool_used = 0;
     uint64_t stg_bit0 = 0; uint32_t stg_bits = 0;
@@ -179,16 +182,18 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         uint64_t v;
         bool bad = false;
         GP_T(0);
-        // ---------------------------------------------------------------- header, wavefront 0 in step (BVG:1003-1058)
+        // ---------------------------------------------------------------- header (BVG:1003-1058) in stages: the counts by wavefront 0 in
+        // step; the copy blocks and the intervals in parallel tasks of kSkipEvery codes when the index holds their entries (every
+        // kSkipEvery-th block / interval of a long section: bit offset + the running sums), else by wavefront 0 in step as well
         uint32_t d = 0, ref = 0, bc = 0, ic = 0, nres = 0, rlen = 0, ivtot = 0;
         uint64_t rlb = 0;
+        // H1: outdegree, reference, block count
         if (wv == 0) {
             uint32_t hfail = 0;
             do {
                 seek(off_x);
                 if (!rd_gamma(v) || v > 0x7FFFFFFFull) { hfail = 0xFFFFFFF5u; break; }
                 d = (uint32_t)v;
-                int64_t extra = d;
                 if (d == 0) break;
                 if (W > 0) {                                                   // readReference (unary), BVG:692-703
                     const uint32_t lz = sclz64(hi);
@@ -198,56 +203,161 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                     ref = (uint32_t)v;
                 }
                 if (ref > 0) {
-                    rlen = nd_d[(uint32_t)(x - ref) & RM];
                     if (!rd_gamma(v) || v > rec_end - (cur < rec_end ? cur : rec_end) + 1) { hfail = 0xFFFFFFF5u; break; }
                     bc = (uint32_t)v;
                     if ((uint64_t)bc + 4 > SCR) { hfail = 0xFFFFFFF2u; break; }
-                    uint64_t tot = 0, copied = 0;
-                    // (the loop is bounded by the count, which the record's length bounds: running off the record's end is checked behind
-                    // it, so that the loop-carried chain stays on the scalar unit -- 64-bit comparisons are vector operations)
-                    for (uint32_t i = 0; i < bc; i++) {                        // copy blocks, BVG:1023-1032, in prefix form
-                        if (!rd_gamma(v)) { bad = true; break; }
-                        const uint64_t b = v + (i ? 1u : 0u);
-                        tot += b; if (!(i & 1u)) copied += b;
-                        put(i, (uint32_t)tot, (uint32_t)copied, 0u);
-                        if (group_full(i, bc) && lane <= (i & 63u)) scr[(i & ~63u) + lane] = MP::pack(st_a, st_b);
-                    }
-                    if (bad || cur > rec_end || tot > rlen) { hfail = 0xFFFFFFF5u; break; }   // blocks running past the referenced list: the literal kernel decides
-                    if (!(bc & 1u)) copied += rlen - tot;                      // BVG:1030
-                    extra = (int64_t)d - (int64_t)copied;
-                    if (extra < 0) { hfail = 0xFFFFFFF5u; break; }
                 }
-                const uint64_t ib = bc;                                        // intervals behind the blocks: left[ic], before[ic + 1], position[ic]
-                if (extra > 0 && minint != 0) {                                // BVG:1037-1058 (always gamma)
-                    if (!rd_gamma(v) || v > (rec_end - (cur < rec_end ? cur : rec_end)) / 2 + 1) { hfail = 0xFFFFFFF5u; break; }
-                    ic = (uint32_t)v;
-                    if (ib + 3ull * ic + 4 > SCR) { hfail = 0xFFFFFFF2u; break; }
-                    int64_t prev = 0, left0 = 0; uint64_t before = 0;
-                    for (uint32_t i = 0; i < ic; i++) {
-                        uint64_t v1, v2;
-                        if (!rd_gamma(v1) || !rd_gamma(v2)) { bad = true; break; }
-                        const int64_t left = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
-                        if (i == 0) left0 = left;
-                        const int64_t len = (int64_t)v2 + minint;
-                        prev = left + len;
-                        put(i, (uint32_t)left, (uint32_t)((uint64_t)left >> 32), (uint32_t)before);
-                        if (group_full(i, ic) && lane <= (i & 63u)) { const uint32_t j = (i & ~63u) + lane; scr[ib + j] = (uint64_t)(T)(((uint64_t)st_b << 32) | st_a); scr[ib + ic + j] = st_c; }
-                        before += (uint64_t)len;
-                    }
-                    extra -= (int64_t)before;
-                    if (lane == 0) scr[ib + 2ull * ic] = before;
-                    if (bad || cur > rec_end || left0 < 0 || before > 0x7FFFFFFFull || extra < 0) { hfail = 0xFFFFFFF5u; break; }
-                    ivtot = (uint32_t)before;
-                }
-                nres = (uint32_t)extra;
             } while (0);
-            if (lane == 0) { hd[0] = d; hd[1] = ref; hd[2] = bc; hd[3] = ic; hd[4] = nres; hd[5] = ivtot; hd[6] = hfail; hd[7] = (uint32_t)cur; hd[8] = (uint32_t)(cur >> 32); }
+            if (lane == 0) { hd[0] = d; hd[1] = ref; hd[2] = bc; hd[6] = hfail; hd[7] = (uint32_t)cur; hd[8] = (uint32_t)(cur >> 32); }
         }
         __syncthreads();
-        d = hd[0]; ref = hd[1]; bc = hd[2]; ic = hd[3]; nres = hd[4]; ivtot = hd[5];
+        d = hd[0]; ref = hd[1]; bc = hd[2];
         if (hd[6]) { failed = true; fail_need = hd[6]; break; }
-        if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];                    // where the residuals start
+        if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];
         if (ref > 0) { rlen = nd_d[(uint32_t)(x - ref) & RM]; rlb = nd_base[(uint32_t)(x - ref) & RM]; }
+        int64_t extra = d;
+        // H2: copy blocks (BVG:1023-1032) in prefix form
+        const uint32_t Eb = bc >= kHdrMin ? (bc - 1u) / kSkipEvery : 0u;       // index entries of this section: 6 slots each
+        const uint32_t eb_first = sk_run; sk_run += 6u * Eb;
+        if (sk_use && sk_run > sk_slots) { failed = true; break; }             // index out of step with the stream
+        if (bc) {
+            __syncthreads();                                                   // (hd is rewritten)
+            if (sk_use && Eb) {
+                for (uint32_t q = tid; q <= Eb; q += GNT) {
+                    const uint32_t i0 = q * kSkipEvery, cnt = q == Eb ? bc - i0 : kSkipEvery;
+                    uint64_t pos = cur, tot = 0, cop = 0;
+                    if (q) { const uint64_t sl = sk_base + eb_first + 6ull * (q - 1u); pos = off_x + rd32(sl); tot = rd32(sl + 2); cop = rd32(sl + 4); if (!(pos > cur && pos < rec_end)) { bad = true; pos = cur; } }
+                    for (uint32_t i = 0; i < cnt && !bad; i++) {
+                        const uint64_t w = gwin64(a.graph, pos);
+                        const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                        if (lz > 31u) { bad = true; break; }
+                        const uint32_t l = 2u * lz + 1u; pos += l;
+                        const uint64_t b = (w >> (64u - l)) - 1u + ((i0 + i) ? 1u : 0u);
+                        tot += b; if (!((i0 + i) & 1u)) cop += b;
+                        scr[i0 + i] = MP::pack((uint32_t)tot, (uint32_t)cop);
+                    }
+                    if (q == Eb) { hd[0] = (uint32_t)pos; hd[1] = (uint32_t)(pos >> 32); hd[2] = (uint32_t)tot; hd[3] = (uint32_t)(tot >> 32); hd[4] = (uint32_t)cop; hd[5] = (uint32_t)(cop >> 32); }
+                }
+                if (bad) atomicOr(&wg_bad, 1u);
+            } else if (wv == 0) {
+                uint64_t tot = 0, copied = 0;
+                // (the loop is bounded by the count, which the record's length bounds: running off the record's end is checked behind it,
+                // so that the loop-carried chain stays on the scalar unit -- 64-bit comparisons are vector operations)
+                for (uint32_t i = 0; i < bc; i++) {
+                    if (sk_fill && Eb && i && (i & (kSkipEvery - 1u)) == 0 && lane == 0) {
+                        const uint64_t sl = sk_base + eb_first + 6ull * (i / kSkipEvery - 1u);
+                        if (sl + 5 < sk_base + sk_slots) { wr32(sl, (uint32_t)(cur - off_x)); wr32(sl + 2, (uint32_t)tot); wr32(sl + 4, (uint32_t)copied); }
+                        if (cur - off_x > 0xFFFFFFFFull) bad = true;
+                    }
+                    if (!rd_gamma(v)) { bad = true; break; }
+                    const uint64_t b = v + (i ? 1u : 0u);
+                    tot += b; if (!(i & 1u)) copied += b;
+                    put(i, (uint32_t)tot, (uint32_t)copied, 0u);
+                    if (group_full(i, bc) && lane <= (i & 63u)) scr[(i & ~63u) + lane] = MP::pack(st_a, st_b);
+                }
+                if (bad) atomicOr(&wg_bad, 1u);
+                if (lane == 0) { hd[0] = (uint32_t)cur; hd[1] = (uint32_t)(cur >> 32); hd[2] = (uint32_t)tot; hd[3] = (uint32_t)(tot >> 32); hd[4] = (uint32_t)copied; hd[5] = (uint32_t)(copied >> 32); }
+            }
+            __syncthreads();
+            if (wg_bad) { failed = true; break; }
+            cur = ((uint64_t)hd[1] << 32) | hd[0];
+            const uint64_t tot = ((uint64_t)hd[3] << 32) | hd[2]; uint64_t copied = ((uint64_t)hd[5] << 32) | hd[4];
+            if (cur > rec_end || tot > rlen) { failed = true; break; }         // blocks running past the referenced list: the literal kernel decides
+            if (!(bc & 1u)) copied += rlen - tot;                              // BVG:1030
+            extra = (int64_t)d - (int64_t)copied;
+            if (extra < 0) { failed = true; break; }
+        }
+        // H3: interval count (always gamma, BVG:1040)
+        const uint64_t ib = bc;                                                // intervals behind the blocks: left[ic], before[ic + 1], position[ic]
+        if (d > 0 && extra > 0 && minint != 0) {
+            __syncthreads();
+            if (wv == 0) {
+                uint32_t hfail = 0;
+                seek(cur);
+                if (!rd_gamma(v) || v > (rec_end - (cur < rec_end ? cur : rec_end)) / 2 + 1) hfail = 0xFFFFFFF5u;
+                else if (ib + 3ull * v + 4 > SCR) hfail = 0xFFFFFFF2u;
+                if (lane == 0) { hd[3] = hfail ? 0u : (uint32_t)v; hd[6] = hfail; hd[7] = (uint32_t)cur; hd[8] = (uint32_t)(cur >> 32); }
+            }
+            __syncthreads();
+            ic = hd[3];
+            if (hd[6]) { failed = true; fail_need = hd[6]; break; }
+            if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];
+        }
+        // H4: intervals (BVG:1042-1058)
+        const uint32_t Ei = ic >= kHdrMin ? (ic - 1u) / kSkipEvery : 0u;       // 8 slots each
+        const uint32_t ei_first = sk_run; sk_run += 8u * Ei;
+        if (sk_use && sk_run > sk_slots) { failed = true; break; }
+        if (ic) {
+            __syncthreads();
+            if (sk_use && Ei) {
+                for (uint32_t q = tid; q <= Ei; q += GNT) {
+                    const uint32_t i0 = q * kSkipEvery, cnt = q == Ei ? ic - i0 : kSkipEvery;
+                    uint64_t pos = cur, before = 0; int64_t prev = 0;
+                    if (q) {
+                        const uint64_t sl = sk_base + ei_first + 8ull * (q - 1u);
+                        pos = off_x + rd32(sl); prev = (int64_t)(((uint64_t)rd32(sl + 4) << 32) | rd32(sl + 2)); before = rd32(sl + 6);
+                        if (!(pos > cur && pos < rec_end)) { bad = true; pos = cur; }
+                    }
+                    for (uint32_t i = 0; i < cnt && !bad; i++) {
+                        uint64_t w = gwin64(a.graph, pos);
+                        uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                        if (lz > 31u) { bad = true; break; }
+                        uint32_t l = 2u * lz + 1u; pos += l;
+                        const uint64_t v1 = (w >> (64u - l)) - 1u;
+                        w = gwin64(a.graph, pos); lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                        if (lz > 31u) { bad = true; break; }
+                        l = 2u * lz + 1u; pos += l;
+                        const uint64_t v2 = (w >> (64u - l)) - 1u;
+                        const int64_t left = (i0 + i) == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
+                        if ((i0 + i) == 0 && left < 0) bad = true;
+                        const int64_t len = (int64_t)v2 + minint;
+                        prev = left + len;
+                        scr[ib + i0 + i] = (uint64_t)(T)left; scr[ib + ic + i0 + i] = before;
+                        before += (uint64_t)len;
+                    }
+                    if (q == Ei) { scr[ib + 2ull * ic] = before; hd[0] = (uint32_t)pos; hd[1] = (uint32_t)(pos >> 32); hd[2] = (uint32_t)before; hd[3] = (uint32_t)(before >> 32); }
+                }
+                if (bad) atomicOr(&wg_bad, 1u);
+            } else if (wv == 0) {
+                int64_t prev = 0, left0 = 0; uint64_t before = 0;
+                for (uint32_t i = 0; i < ic; i++) {
+                    if (sk_fill && Ei && i && (i & (kSkipEvery - 1u)) == 0 && lane == 0) {
+                        const uint64_t sl = sk_base + ei_first + 8ull * (i / kSkipEvery - 1u);
+                        if (sl + 7 < sk_base + sk_slots) { wr32(sl, (uint32_t)(cur - off_x)); wr32(sl + 2, (uint32_t)(uint64_t)prev); wr32(sl + 4, (uint32_t)((uint64_t)prev >> 32)); wr32(sl + 6, (uint32_t)before); }
+                        if (cur - off_x > 0xFFFFFFFFull) bad = true;
+                    }
+                    uint64_t v1, v2;
+                    if (!rd_gamma(v1) || !rd_gamma(v2)) { bad = true; break; }
+                    const int64_t left = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
+                    if (i == 0) left0 = left;
+                    const int64_t len = (int64_t)v2 + minint;
+                    prev = left + len;
+                    put(i, (uint32_t)left, (uint32_t)((uint64_t)left >> 32), (uint32_t)before);
+                    if (group_full(i, ic) && lane <= (i & 63u)) { const uint32_t j = (i & ~63u) + lane; scr[ib + j] = (uint64_t)(T)(((uint64_t)st_b << 32) | st_a); scr[ib + ic + j] = st_c; }
+                    before += (uint64_t)len;
+                }
+                if (bad || left0 < 0) atomicOr(&wg_bad, 1u);
+                if (lane == 0) { scr[ib + 2ull * ic] = before; hd[0] = (uint32_t)cur; hd[1] = (uint32_t)(cur >> 32); hd[2] = (uint32_t)before; hd[3] = (uint32_t)(before >> 32); }
+            }
+            __syncthreads();
+            if (wg_bad) { failed = true; break; }
+            cur = ((uint64_t)hd[1] << 32) | hd[0];
+            const uint64_t before = ((uint64_t)hd[3] << 32) | hd[2];
+            extra -= (int64_t)before;
+            if (cur > rec_end || before > 0x7FFFFFFFull || extra < 0) { failed = true; break; }
+            ivtot = (uint32_t)before;
+        }
+        if (d > 0) nres = (uint32_t)extra;
+        if (wv == 0 && nres && !(sk_use && nres >= kSkipMin)) seek(cur);        // the residuals follow in step: wavefront 0's buffer goes back to the cursor
+        const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) / kSkipEvery : 0u;    // index entries of the residuals: 2 slots (+ a value) each
+        const uint32_t efirst = sk_run;
+        sk_run += 2u * cntE;
+        if (a.skip_mode == 1) {                                                 // the index build only counts entries here: the header walk was all it needs
+            __syncthreads();
+            if (tid == 0) { nd_base[(uint32_t)x & RM] = 0; nd_d[(uint32_t)x & RM] = d; }
+            __syncthreads();
+            continue;
+        }
         const uint64_t* const B = scr; const uint64_t* const IL = scr + bc; const uint64_t* const IC = scr + bc + ic; uint64_t* const IP = scr + bc + 2ull * ic + 1;
 
         GP_T(1);
@@ -283,9 +393,6 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
 
         GP_T(2);
         // ---------------------------------------------------------------- residuals (BVG:902-935)
-        const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) / kSkipEvery : 0u;
-        const uint32_t efirst = sk_run;
-        sk_run += 2u * cntE;
         if (nres > 0) {
             if (sk_use && cntE) {
                 if (sk_run > sk_slots) { failed = true; break; }               // index out of step with the stream
