@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a GPU test that stops (a kernel that never drains, a host thread that never returns) should end with the stacks of every
+    # thread on stderr instead of holding the box until the caller's limit kills the run without a trace
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for it in items:
+        if "gpu" in it.keywords and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def cnr_golden():
     """The reference's own expected answer (BVGraphTest.testLarge): list of int64 arrays, one per node."""

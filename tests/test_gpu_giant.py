@@ -36,10 +36,19 @@ def _check(W, O, st, ranges=(), scans=2):
 @pytest.fixture
 def every_block(monkeypatch):
     monkeypatch.setenv("BVG_GIANT", "2")
+    monkeypatch.setenv("BVG_DEBUG", "1")                      # names the tiers on stderr: see _none_left_to_the_generic_kernel
+
+
+def _none_left_to_the_generic_kernel(capfd):
+    """a well-formed graph gives the giant kernel nothing to refuse (a refusal is not an error -- the generic kernel then decodes
+    the block -- so only the tier names tell)"""
+    err = capfd.readouterr().err
+    assert "tier2a (giant)" in err, "the giant kernel did not run"
+    assert "tier2 (generic)" not in err, [l for l in err.splitlines() if "tier2" in l][:6]
 
 
 @pytest.mark.parametrize("shape", ["eu", "web", "nowindow", "minint2"])
-def test_every_block_through_the_giant_kernel(W, tools, oracle, every_block, shape):
+def test_every_block_through_the_giant_kernel(W, tools, oracle, every_block, capfd, shape):
     if shape == "eu": st = tools.synth_store(6000, seed=5, synth=tools.eu_like(), threads=4)
     elif shape == "web": st = tools.synth_store(20000, seed=6, synth=tools.web_like(), threads=4)
     elif shape == "nowindow": st = tools.synth_store(8000, seed=7, params=W.default_params(window_size=0, max_ref_count=0), synth=tools.web_like(), threads=4)
@@ -47,9 +56,10 @@ def test_every_block_through_the_giant_kernel(W, tools, oracle, every_block, sha
     n = st.params.nodes
     res = _check(W, oracle, st, ranges=[(0, 1), (n // 3, n), (n - 1, n), (100, 100)])
     assert res[0]["slow_blocks"] > 0
+    _none_left_to_the_generic_kernel(capfd)
 
 
-def test_cnr2000_through_the_giant_kernel(W, cnr_csr, every_block):
+def test_cnr2000_through_the_giant_kernel(W, cnr_csr, every_block, capfd):
     from conftest import CNR
     g = W.BVGraph.load(CNR)
     gdeg, gsucc = cnr_csr
@@ -58,6 +68,7 @@ def test_cnr2000_through_the_giant_kernel(W, cnr_csr, every_block):
     deg, succ = g.decode_range(0, g.num_nodes())
     assert np.array_equal(deg, gdeg) and np.array_equal(succ, gsucc)
     g.close()
+    _none_left_to_the_generic_kernel(capfd)
 
 
 def _giant_graph(rng, n, giants, deg):

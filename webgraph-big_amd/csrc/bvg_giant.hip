@@ -63,10 +63,12 @@ __device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t 
 
 #ifdef BVG_PROF
 #define GP_T(i) do { gp_t[i] = clock64(); } while (0)
+#define GP_WHY(n) do { if (tid == 0 && (a.dbg & 1024u)) printf("[giant] block %u node %lld refused at site %d (hd6 %x)\n", bid, (long long)x, n, hd[6]); } while (0)
 #define GP_REPORT() do { if (tid == 0 && d > 100000u && (a.dbg & 512u)) printf("[giant] node %lld d %u ref %u bc %u ic %u nres %u | Kcycles: header %lld room %lld residuals %lld Z1a %lld Z1b %lld Z2 %lld\n", (long long)x, d, ref, bc, ic, nres, \
     (long long)(gp_t[1] - gp_t[0]) >> 10, (long long)(gp_t[2] - gp_t[1]) >> 10, (long long)(gp_t[3] - gp_t[2]) >> 10, (long long)(gp_t[4] - gp_t[3]) >> 10, (long long)(gp_t[5] - gp_t[4]) >> 10, (long long)(gp_t[6] - gp_t[5]) >> 10); } while (0)
 #else
 #define GP_T(i) do {} while (0)
+#define GP_WHY(n) do {} while (0)
 #define GP_REPORT() do {} while (0)
 #endif
 
@@ -212,14 +214,14 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         }
         __syncthreads();
         d = hd[0]; ref = hd[1]; bc = hd[2];
-        if (hd[6]) { failed = true; fail_need = hd[6]; break; }
+        if (hd[6]) { failed = true; GP_WHY(1); fail_need = hd[6]; break; }
         if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];
         if (ref > 0) { rlen = nd_d[(uint32_t)(x - ref) & RM]; rlb = nd_base[(uint32_t)(x - ref) & RM]; }
         int64_t extra = d;
         // H2: copy blocks (BVG:1023-1032) in prefix form
         const uint32_t Eb = bc >= kHdrMin ? (bc - 1u) / kSkipEvery : 0u;       // index entries of this section: 6 slots each
         const uint32_t eb_first = sk_run; sk_run += 6u * Eb;
-        if (sk_use && sk_run > sk_slots) { failed = true; break; }             // index out of step with the stream
+        if (sk_use && sk_run > sk_slots) { failed = true; GP_WHY(2); break; }             // index out of step with the stream
         if (bc) {
             __syncthreads();                                                   // (hd is rewritten)
             if (sk_use && Eb) {
@@ -259,13 +261,16 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (lane == 0) { hd[0] = (uint32_t)cur; hd[1] = (uint32_t)(cur >> 32); hd[2] = (uint32_t)tot; hd[3] = (uint32_t)(tot >> 32); hd[4] = (uint32_t)copied; hd[5] = (uint32_t)(copied >> 32); }
             }
             __syncthreads();
-            if (wg_bad) { failed = true; break; }
+            if (wg_bad) { failed = true; GP_WHY(3); break; }
             cur = ((uint64_t)hd[1] << 32) | hd[0];
             const uint64_t tot = ((uint64_t)hd[3] << 32) | hd[2]; uint64_t copied = ((uint64_t)hd[5] << 32) | hd[4];
-            if (cur > rec_end || tot > rlen) { failed = true; break; }         // blocks running past the referenced list: the literal kernel decides
+            if (cur > rec_end || tot > rlen) { failed = true; GP_WHY(4); break; }         // blocks running past the referenced list: the literal kernel decides
             if (!(bc & 1u)) copied += rlen - tot;                              // BVG:1030
             extra = (int64_t)d - (int64_t)copied;
-            if (extra < 0) { failed = true; break; }
+            if (extra < 0) { failed = true; GP_WHY(5); break; }
+        } else if (ref > 0) {                                                  // no blocks: the whole referenced list is copied (BVG:1030)
+            extra = (int64_t)d - (int64_t)rlen;
+            if (extra < 0) { failed = true; GP_WHY(14); break; }
         }
         // H3: interval count (always gamma, BVG:1040)
         const uint64_t ib = bc;                                                // intervals behind the blocks: left[ic], before[ic + 1], position[ic]
@@ -280,13 +285,13 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
             }
             __syncthreads();
             ic = hd[3];
-            if (hd[6]) { failed = true; fail_need = hd[6]; break; }
+            if (hd[6]) { failed = true; GP_WHY(6); fail_need = hd[6]; break; }
             if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];
         }
         // H4: intervals (BVG:1042-1058)
         const uint32_t Ei = ic >= kHdrMin ? (ic - 1u) / kSkipEvery : 0u;       // 8 slots each
         const uint32_t ei_first = sk_run; sk_run += 8u * Ei;
-        if (sk_use && sk_run > sk_slots) { failed = true; break; }
+        if (sk_use && sk_run > sk_slots) { failed = true; GP_WHY(7); break; }
         if (ic) {
             __syncthreads();
             if (sk_use && Ei) {
@@ -340,11 +345,11 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (lane == 0) { scr[ib + 2ull * ic] = before; hd[0] = (uint32_t)cur; hd[1] = (uint32_t)(cur >> 32); hd[2] = (uint32_t)before; hd[3] = (uint32_t)(before >> 32); }
             }
             __syncthreads();
-            if (wg_bad) { failed = true; break; }
+            if (wg_bad) { failed = true; GP_WHY(8); break; }
             cur = ((uint64_t)hd[1] << 32) | hd[0];
             const uint64_t before = ((uint64_t)hd[3] << 32) | hd[2];
             extra -= (int64_t)before;
-            if (cur > rec_end || before > 0x7FFFFFFFull || extra < 0) { failed = true; break; }
+            if (cur > rec_end || before > 0x7FFFFFFFull || extra < 0) { failed = true; GP_WHY(9); break; }
             ivtot = (uint32_t)before;
         }
         if (d > 0) nres = (uint32_t)extra;
@@ -385,7 +390,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
             __syncthreads();
             if (ref > 0) rlb = nd_base[(uint32_t)(x - ref) & RM];
         }
-        if (pool_used + (uint64_t)d + nres + 1 > CAP) { failed = true; fail_need = 0xFFFFFFF2u; break; }
+        if (pool_used + (uint64_t)d + nres + 1 > CAP) { failed = true; GP_WHY(10); fail_need = 0xFFFFFFF2u; break; }
         const uint64_t base = pool_used;
         T* const out = pool + base;
         T* const rt = pool + (CAP - nres - 1);
@@ -395,7 +400,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         // ---------------------------------------------------------------- residuals (BVG:902-935)
         if (nres > 0) {
             if (sk_use && cntE) {
-                if (sk_run > sk_slots) { failed = true; break; }               // index out of step with the stream
+                if (sk_run > sk_slots) { failed = true; GP_WHY(11); break; }               // index out of step with the stream
                 __syncthreads();
                 const uint32_t Ttot = cntE + 1u;
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += GNT) {
@@ -455,7 +460,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         if (tid == 0 && nres + 1u > 0) rt[nres] = sentinel<T>();               // guard behind the residual positions
         if (bad) atomicOr(&wg_bad, 1u);
         __syncthreads();
-        if (wg_bad) { failed = true; break; }
+        if (wg_bad) { failed = true; GP_WHY(12); break; }
 
         GP_T(3);
         // ---------------------------------------------------------------- emission by output position (BVG:1062-1090)
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         __syncthreads();
         GP_T(6);
         GP_REPORT();
-        if (wg_bad) { failed = true; break; }
+        if (wg_bad) { failed = true; GP_WHY(13); break; }
         if (tid == 0) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
         pool_used = base + d;
         if (rep) { blk_arcs += d; blk_nodes += 1; }
