@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__built
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
 // leading zeros of a 64-bit value held in scalar registers (opaque to the optimiser, which would otherwise turn `lz < 32` into a
 // 64-bit comparison: a VECTOR instruction whose result the scalar loop has to wait for); 0xFFFFFFFF for 0
-__device__ __forceinline__ uint32_t sclz64(uint64_t w) { uint32_t r; asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(w)); return r; }
+__device__ __forceinline__ uint32_t sclz64(uint64_t w) { uint32_t r; asm volatile("" : "+s"(w)); asm("s_flbit_i32_b64 %0, %1" : "=s"(r) : "s"(w)); return r; }   // (pinned to a register pair first: a folded constant is no operand)
 // first index in [from, n) at which a monotone predicate turns true (n if never): doubling steps from `from`, then bisection
 template <typename F> __device__ __forceinline__ uint32_t gallop_first(uint32_t from, uint32_t n, F pred) {
     uint32_t b = from, st = 1;
@@ -53,6 +53,11 @@ template <typename F> __device__ __forceinline__ uint32_t gallop_first(uint32_t 
     uint32_t lo = b, hi = b + st - 1u < n ? b + st - 1u : n;
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (!pred(mid)) lo = mid + 1; else hi = mid; }
     return lo;
+}
+__device__ __forceinline__ uint64_t gwave_incl_scan64(uint64_t v, uint32_t lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t t = __shfl_up(v, o, 64); if ((int)lane >= o) v += t; }
+    return v;
 }
 // number of elements <= v in a sorted array
 __device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t n, uint64_t v) {
@@ -176,6 +181,31 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
     };
     // true for the lanes that store now: entry i was the last of its group of 64 (or the last of all)
     auto group_full = [&](uint32_t i, uint32_t n) -> bool { return (i & 63u) == 63u || i + 1u == n; };   // scalar: the 64 entries are stored now
+    // ---- code boundaries resolved in the wavefront (long sections without index entries: first scan, index build).  The next 128 bits
+    // of the stream sit in (hi, lo); lane b decodes the code that WOULD start at bit b of them (length and value); the codes that
+    // really start there are the chain 0 -> len[0] -> ... followed on the scalar side with v_readlane (five scalar instructions per
+    // code instead of the ~45 of the walk in step); the chain's lanes then hold one chunk of up to 64 consecutive codes, and prefix
+    // scans over them turn gaps into values.
+    auto load128 = [&](uint64_t pos) {
+        if (!(stg_bits && pos >= stg_bit0 && (pos + 192 <= stg_bit0 + stg_bits || stg_bit0 + stg_bits >= a.padded_bytes * 8ull))) { seek(pos); }
+        const uint32_t rel = (uint32_t)(pos - stg_bit0), wi = rel >> 5, sh = rel & 31u, m = kGStageWords - 1;
+        const uint32_t d0 = uni32(stage[wi & m]), d1 = uni32(stage[(wi + 1) & m]), d2 = uni32(stage[(wi + 2) & m]), d3 = uni32(stage[(wi + 3) & m]), d4 = uni32(stage[(wi + 4) & m]);
+        hi = ((uint64_t)d0 << 32) | d1; lo = ((uint64_t)d2 << 32) | d3;
+        if (sh) { hi = (hi << sh) | (lo >> (64u - sh)); lo = (lo << sh) | ((uint64_t)d4 >> (32u - sh)); }
+        cur = pos;
+    };
+    auto lane_window = [&]() -> uint64_t { return lane ? (hi << lane) | (lo >> (64u - lane)) : hi; };
+    // the chain through the per-lane lengths: mask of the lanes where a code starts, their number (at most `want`), the bits they span
+    auto follow_chain = [&](uint32_t lenv, uint32_t want, uint64_t& mask, uint32_t& n, uint32_t& span) -> bool {
+        mask = 0; n = 0; uint32_t pos = 0;
+        while (pos < 64u && n < want) {
+            const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)pos);
+            if (l == 0) return false;
+            mask |= 1ull << pos; pos += l; n++;
+        }
+        span = pos;
+        return true;
+    };
 
     for (int64_t x = hs; x < e; x++) {
         const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
@@ -213,10 +243,10 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
             if (lane == 0) { hd[0] = d; hd[1] = ref; hd[2] = bc; hd[6] = hfail; hd[7] = (uint32_t)cur; hd[8] = (uint32_t)(cur >> 32); }
         }
         __syncthreads();
-        d = hd[0]; ref = hd[1]; bc = hd[2];
-        if (hd[6]) { failed = true; GP_WHY(1); fail_need = hd[6]; break; }
-        if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];
-        if (ref > 0) { rlen = nd_d[(uint32_t)(x - ref) & RM]; rlb = nd_base[(uint32_t)(x - ref) & RM]; }
+        d = uni32(hd[0]); ref = uni32(hd[1]); bc = uni32(hd[2]);
+        if (uni32(hd[6])) { failed = true; GP_WHY(1); fail_need = uni32(hd[6]); break; }
+        if (wv != 0) cur = ((uint64_t)uni32(hd[8]) << 32) | uni32(hd[7]);
+        if (ref > 0) { rlen = uni32(nd_d[(uint32_t)(x - ref) & RM]); rlb = uni64(nd_base[(uint32_t)(x - ref) & RM]); }
         int64_t extra = d;
         // H2: copy blocks (BVG:1023-1032) in prefix form
         const uint32_t Eb = bc >= kHdrMin ? (bc - 1u) / kSkipEvery : 0u;       // index entries of this section: 6 slots each
@@ -243,6 +273,35 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (bad) atomicOr(&wg_bad, 1u);
             } else if (wv == 0) {
                 uint64_t tot = 0, copied = 0;
+                if (bc >= kHdrMin) {                                           // boundaries resolved in the wavefront, a chunk of codes per step
+                    bool lbad = false, cbad = false;                           // (per lane / wave-uniform: the loop's own exits stay uniform)
+                    for (uint32_t i = 0; i < bc;) {
+                        load128(cur);
+                        const uint64_t w = lane_window();
+                        const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                        const uint32_t len = lz < 32u ? 2u * lz + 1u : 0u;
+                        const uint32_t val = len ? (uint32_t)((w >> (64u - len)) - 1u) : 0u;
+                        uint64_t mask; uint32_t n, span;
+                        if (!follow_chain(len, bc - i, mask, n, span)) { cbad = true; break; }
+                        const bool on = (mask >> lane) & 1ull;
+                        const uint32_t gi = i + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        const uint32_t bv = on ? val + (gi ? 1u : 0u) : 0u, ev = (on && !(gi & 1u)) ? bv : 0u;
+                        const uint32_t ti = wave_incl_scan32(bv), ci = wave_incl_scan32(ev);
+                        if (on) {
+                            const uint64_t t = tot + ti, c = copied + ci;
+                            scr[gi] = MP::pack((uint32_t)t, (uint32_t)c);
+                            if (sk_fill && Eb && gi && (gi & (kSkipEvery - 1u)) == 0) {
+                                const uint64_t sl = sk_base + eb_first + 6ull * (gi / kSkipEvery - 1u), rel = cur + lane - off_x;
+                                if (sl + 5 < sk_base + sk_slots) { wr32(sl, (uint32_t)rel); wr32(sl + 2, (uint32_t)(t - bv)); wr32(sl + 4, (uint32_t)(c - ev)); }
+                                if (rel > 0xFFFFFFFFull) lbad = true;
+                            }
+                        }
+                        tot += lane_get(ti, 63); copied += lane_get(ci, 63);
+                        i += n; cur += span;
+                    }
+                    if (cbad || ballot(lbad)) bad = true;
+                    seek(cur);                                                 // the walk in step goes on from here
+                } else
                 // (the loop is bounded by the count, which the record's length bounds: running off the record's end is checked behind it,
                 // so that the loop-carried chain stays on the scalar unit -- 64-bit comparisons are vector operations)
                 for (uint32_t i = 0; i < bc; i++) {
@@ -261,9 +320,9 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (lane == 0) { hd[0] = (uint32_t)cur; hd[1] = (uint32_t)(cur >> 32); hd[2] = (uint32_t)tot; hd[3] = (uint32_t)(tot >> 32); hd[4] = (uint32_t)copied; hd[5] = (uint32_t)(copied >> 32); }
             }
             __syncthreads();
-            if (wg_bad) { failed = true; GP_WHY(3); break; }
-            cur = ((uint64_t)hd[1] << 32) | hd[0];
-            const uint64_t tot = ((uint64_t)hd[3] << 32) | hd[2]; uint64_t copied = ((uint64_t)hd[5] << 32) | hd[4];
+            if (uni32(wg_bad)) { failed = true; GP_WHY(3); break; }
+            cur = ((uint64_t)uni32(hd[1]) << 32) | uni32(hd[0]);
+            const uint64_t tot = ((uint64_t)uni32(hd[3]) << 32) | uni32(hd[2]); uint64_t copied = ((uint64_t)uni32(hd[5]) << 32) | uni32(hd[4]);
             if (cur > rec_end || tot > rlen) { failed = true; GP_WHY(4); break; }         // blocks running past the referenced list: the literal kernel decides
             if (!(bc & 1u)) copied += rlen - tot;                              // BVG:1030
             extra = (int64_t)d - (int64_t)copied;
@@ -284,9 +343,9 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (lane == 0) { hd[3] = hfail ? 0u : (uint32_t)v; hd[6] = hfail; hd[7] = (uint32_t)cur; hd[8] = (uint32_t)(cur >> 32); }
             }
             __syncthreads();
-            ic = hd[3];
-            if (hd[6]) { failed = true; GP_WHY(6); fail_need = hd[6]; break; }
-            if (wv != 0) cur = ((uint64_t)hd[8] << 32) | hd[7];
+            ic = uni32(hd[3]);
+            if (uni32(hd[6])) { failed = true; GP_WHY(6); fail_need = uni32(hd[6]); break; }
+            if (wv != 0) cur = ((uint64_t)uni32(hd[8]) << 32) | uni32(hd[7]);
         }
         // H4: intervals (BVG:1042-1058)
         const uint32_t Ei = ic >= kHdrMin ? (ic - 1u) / kSkipEvery : 0u;       // 8 slots each
@@ -325,6 +384,42 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (bad) atomicOr(&wg_bad, 1u);
             } else if (wv == 0) {
                 int64_t prev = 0, left0 = 0; uint64_t before = 0;
+                if (ic >= kHdrMin) {
+                    // the 2 * ic gamma codes alternate (gap to the left end, length - minInterval); over their chain, a running sum S of
+                    // {1 + gap | length} makes S the left end at a gap code and the interval's end at a length code (BVG:1042-1058)
+                    bool lbad = false, cbad = false;                           // (per lane / wave-uniform: `bad` itself may have been set per lane before)
+                    const uint32_t ctot = 2u * ic;
+                    for (uint32_t cdone = 0; cdone < ctot;) {
+                        load128(cur);
+                        const uint64_t w = lane_window();
+                        const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                        const uint32_t len = lz < 32u ? 2u * lz + 1u : 0u;
+                        const uint64_t val = len ? (w >> (64u - len)) - 1u : 0u;
+                        uint64_t mask; uint32_t n, span;
+                        if (!follow_chain(len, ctot - cdone, mask, n, span)) { cbad = true; break; }
+                        const bool on = (mask >> lane) & 1ull;
+                        const uint32_t gc = cdone + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        const bool isgap = on && !(gc & 1u), islen = on && (gc & 1u);
+                        const uint32_t iv = gc >> 1;                           // the interval this code belongs to
+                        const int64_t c = !on ? 0 : isgap ? (gc == 0 ? x + nat2int64(val) : 1 + (int64_t)val) : (int64_t)val + minint;
+                        const uint64_t lc = islen ? val + minint : 0ull;
+                        const int64_t S = prev + (int64_t)gwave_incl_scan64((uint64_t)c, lane);
+                        const uint64_t Bf = before + gwave_incl_scan64(lc, lane);   // at a gap code: the elements of the intervals before it
+                        if (isgap) {
+                            if (gc == 0 && S < 0) lbad = true;
+                            scr[ib + iv] = (uint64_t)(T)S; scr[ib + ic + iv] = Bf;
+                            if (sk_fill && Ei && iv && (iv & (kSkipEvery - 1u)) == 0) {
+                                const uint64_t sl = sk_base + ei_first + 8ull * (iv / kSkipEvery - 1u), rel = cur + lane - off_x; const uint64_t pv = (uint64_t)(S - c);
+                                if (sl + 7 < sk_base + sk_slots) { wr32(sl, (uint32_t)rel); wr32(sl + 2, (uint32_t)pv); wr32(sl + 4, (uint32_t)(pv >> 32)); wr32(sl + 6, (uint32_t)Bf); }
+                                if (rel > 0xFFFFFFFFull) lbad = true;
+                            }
+                        }
+                        prev = (int64_t)lane_get64((uint64_t)S, 63); before = lane_get64(Bf, 63);
+                        cdone += n; cur += span;
+                    }
+                    if (cbad || ballot(lbad)) bad = true;
+                    seek(cur);
+                } else
                 for (uint32_t i = 0; i < ic; i++) {
                     if (sk_fill && Ei && i && (i & (kSkipEvery - 1u)) == 0 && lane == 0) {
                         const uint64_t sl = sk_base + ei_first + 8ull * (i / kSkipEvery - 1u);
@@ -345,9 +440,9 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
                 if (lane == 0) { scr[ib + 2ull * ic] = before; hd[0] = (uint32_t)cur; hd[1] = (uint32_t)(cur >> 32); hd[2] = (uint32_t)before; hd[3] = (uint32_t)(before >> 32); }
             }
             __syncthreads();
-            if (wg_bad) { failed = true; GP_WHY(8); break; }
-            cur = ((uint64_t)hd[1] << 32) | hd[0];
-            const uint64_t before = ((uint64_t)hd[3] << 32) | hd[2];
+            if (uni32(wg_bad)) { failed = true; GP_WHY(8); break; }
+            cur = ((uint64_t)uni32(hd[1]) << 32) | uni32(hd[0]);
+            const uint64_t before = ((uint64_t)uni32(hd[3]) << 32) | uni32(hd[2]);
             extra -= (int64_t)before;
             if (cur > rec_end || before > 0x7FFFFFFFull || extra < 0) { failed = true; GP_WHY(9); break; }
             ivtot = (uint32_t)before;
@@ -433,6 +528,39 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
             } else if (wv == 0) {
                 // wavefront 0 in step from the sliding window (64 values stored at a time); the index build records every kSkipEvery-th start
                 T r = (T)x;
+                if (nres >= kHdrMin) {                                         // boundaries resolved in the wavefront (see load128)
+                    bool lbad = false, cbad = false;
+                    for (uint32_t t = 0; t < nres;) {
+                        load128(cur);
+                        const uint64_t w = lane_window();
+                        uint32_t len = 0; uint64_t val = 0;
+                        if (zfast) { uint32_t v32; len = zeta_fast32((uint32_t)(w >> 32), zk, v32); val = v32; }
+                        if (len == 0) len = zeta64(w, zk, val);
+                        uint64_t mask; uint32_t n, span;
+                        if (!follow_chain(len, nres - t, mask, n, span)) { cbad = true; break; }
+                        const bool on = (mask >> lane) & 1ull;
+                        const uint32_t gt = t + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                        const uint64_t c = !on ? 0ull : gt == 0 ? (uint64_t)nat2int64(val) : 1ull + val;
+                        const uint64_t S = gwave_incl_scan64(c, lane);
+                        if (on) {
+                            const T rv = (T)(r + (T)S);
+                            rt[gt] = rv;
+                            if (sk_fill && cntE && gt && (gt & (kSkipEvery - 1u)) == 0) {
+                                const uint64_t sl = sk_base + efirst + 2ull * (gt / kSkipEvery - 1u), rel = cur + lane - off_x;
+                                if (sl + 1 < sk_base + sk_slots) {
+                                    wr32(sl, (uint32_t)rel);
+                                    const T before_v = (T)(rv - (T)c);
+                                    if (sizeof(T) == 8) *reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.skip_val) + sl * 8ull) = (uint64_t)before_v;
+                                    else reinterpret_cast<uint32_t*>(a.skip_val)[sl] = (uint32_t)before_v;
+                                }
+                                if (rel > 0xFFFFFFFFull) lbad = true;
+                            }
+                        }
+                        r = (T)(r + (T)lane_get64(S, 63));
+                        t += n; cur += span;
+                    }
+                    if (cbad || ballot(lbad)) bad = true;
+                } else
                 for (uint32_t t = 0; t < nres; t++) {
                     if (sk_fill && cntE && t && (t & (kSkipEvery - 1u)) == 0 && lane == 0) {
                         const uint64_t sl = sk_base + efirst + 2ull * (t / kSkipEvery - 1u);
@@ -460,7 +588,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         if (tid == 0 && nres + 1u > 0) rt[nres] = sentinel<T>();               // guard behind the residual positions
         if (bad) atomicOr(&wg_bad, 1u);
         __syncthreads();
-        if (wg_bad) { failed = true; GP_WHY(12); break; }
+        if (uni32(wg_bad)) { failed = true; GP_WHY(12); break; }
 
         GP_T(3);
         // ---------------------------------------------------------------- emission by output position (BVG:1062-1090)
@@ -572,7 +700,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         __syncthreads();
         GP_T(6);
         GP_REPORT();
-        if (wg_bad) { failed = true; GP_WHY(13); break; }
+        if (uni32(wg_bad)) { failed = true; GP_WHY(13); break; }
         if (tid == 0) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
         pool_used = base + d;
         if (rep) { blk_arcs += d; blk_nodes += 1; }
