@@ -4,12 +4,15 @@
 // decode_kernel<SLOW>) follows the reference's iterators literally with ONE lane per list: ~1 us per successor, so a handful of
 // such lists takes longer than the rest of the graph.  Here one workgroup of 1024 threads walks its block node by node and
 // every node is decoded by the whole workgroup, everything in a per-workgroup area of global memory:
-//   * the record header, the copy blocks and the intervals (BVG:1015-1058) are decoded by wavefront 0 in step, on the scalar unit,
-//     from a register bit buffer over a sliding LDS window of the stream (64 entries stored per instruction), copy blocks in
-//     prefix form, intervals as {left, elements before};
-//   * the residuals (ResidualLongIterator, BVG:902-935) are cut at the entries of the residual skip index into tasks of
-//     <= kSkipEvery gaps, one per thread, read straight from the stream in global memory; without the index (first scan, index
-//     build) wavefront 0 decodes them in step like the header;
+//   * the counts of the record header (BVG:1003-1021, 1040) are decoded by wavefront 0 in step, on the scalar unit, from a register
+//     bit buffer over a sliding LDS window of the stream;
+//   * the copy blocks (BVG:1023-1032, kept in prefix form), the intervals (BVG:1042-1058, kept as {left, elements before}) and the
+//     residuals (ResidualLongIterator, BVG:902-935) are cut at the entries of the skip index -- every kSkipEvery-th code of a long
+//     section: its bit offset and the running sums before it -- into tasks of <= kSkipEvery codes, one per thread, read straight
+//     from the stream in global memory;
+//   * where the index has no entries yet (first scan, index build, BVG_NOSKIP) wavefront 0 resolves the code boundaries itself: lane
+//     b decodes the code that would start at bit b of the next 128 bits, the chain of the codes that really start there is followed
+//     with v_readlane, and prefix scans over its lanes turn up to 64 gaps per step into values (sections under 48 codes: in step);
 //   * the list is put together by output POSITION as in the row kernels (bvg_rows.hip): every extra (interval, residual) finds
 //     its place by binary searches (extras below it + copied elements below it: lower bound in the referenced list, rank under
 //     the copy mask), then 1024 equal tasks of consecutive positions fill in the kept elements of the referenced list
