@@ -92,6 +92,29 @@ def test_errors_map_to_reference_exceptions(W, small):
         W.BVGraph.from_memory(W.default_params(nodes=3), b"\x80", None)    # offsets derived from the stream: it ends after 1 node
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_offsets_index_packed_and_plain(W, tools, oracle, monkeypatch, wide):
+    """The index lives in HBM packed (32-bit distance per node + a 64-bit base per 1 024 nodes); BVG_WIDE_OFFSETS=1 keeps the plain
+    array (also the fall-back when a distance does not fit).  Both give back the offsets they were given and decode the same."""
+    if wide: monkeypatch.setenv("BVG_WIDE_OFFSETS", "1")
+    st = tools.synth_store(7000, seed=12, chunk_nodes=1024, threads=2)          # > 6 groups of 1 024 nodes, the last one partial
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    assert np.array_equal(g.offsets(), st.offsets)
+    r, o = g.scan(), og.scan()
+    assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"])
+    for a, b in [(1023, 1025), (2047, 2049), (6999, 7000), (0, 7000)]:          # ranges across the group boundaries
+        ra, oa = g.scan(a, b), og.scan(a, b)
+        assert (ra["arcs"], ra["chk"], ra["graph_bytes"]) == (oa["arcs"], oa["chk"], (int(st.offsets[b]) + 7) // 8 - int(st.offsets[a]) // 8), (a, b)
+    deg, succ = g.decode_range(1000, 3100)
+    odeg, osucc = og.decode_range(1000, 3100)
+    assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc)
+    t = g.tile(3)                                                               # tiling writes the packed form directly
+    assert np.array_equal(t.offsets(), np.concatenate([st.offsets[:-1] + k * st.offsets[-1] for k in range(3)] + [[3 * st.offsets[-1]]]).astype(np.uint64))
+    assert t.scan()["arcs"] == 3 * o["arcs"]
+    t.close(); g.close()
+
+
 def test_offsets_and_outdegrees_by_products(small):
     g, og, lists, st = small
     assert np.array_equal(g.offsets(), st.offsets)
