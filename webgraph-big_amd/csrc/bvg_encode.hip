@@ -162,36 +162,62 @@ __global__ void enc_sizes_kernel(EncParams p, const uint64_t* adj_off, const int
     sizes[idx] = out;
 }
 
-// E2: the sequential choice, one lane per chunk (BVG:2254-2270).  best[x] = chosen reference; recbits[x] = bits of the whole record.
-__global__ void enc_choose_kernel(EncParams p, const uint64_t* adj_off, const uint32_t* sizes, uint8_t* best, int32_t* recbits) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// E2: the sequential choice (BVG:2254-2270), one WAVEFRONT per chunk.  The choice for node x needs the chain lengths of the W nodes
+// before it, so a chunk is a serial walk -- but not a walk against global memory: the size table of 64 nodes at a time is staged in
+// LDS with coalesced loads, lane r weighs reference r (admissible? its size), a wave minimum over {size, r} picks the cheapest with
+// the nearest winning ties, lane 0 updates the chain-length ring, and the 64 results leave in one store.  ~0.1 us per node instead of
+// the ~2 us of one lane chasing the table through HBM (a single-range store of 1 M nodes: 2.2 s -> 0.1 s).
+// best[x] = chosen reference; recbits[x] = bits of the whole record.
+__global__ void __launch_bounds__(64) enc_choose_kernel(EncParams p, const uint64_t* adj_off, const uint32_t* sizes, uint8_t* best, int32_t* recbits) {
+    extern __shared__ uint32_t enc_lds[];                                  // tile[64][cyc] | refc[cyc] | d[64] | best[64] | bits[64]
+    const int cyc = p.W + 1;
+    uint32_t* const tile = enc_lds;
+    int32_t* const refc = reinterpret_cast<int32_t*>(enc_lds + 64 * cyc);
+    uint32_t* const dl = enc_lds + 64 * cyc + cyc;
+    uint32_t* const bl = dl + 64;
+    uint32_t* const rb = bl + 64;
+    const unsigned lane = threadIdx.x;
+    const int64_t c = blockIdx.x;
     const int64_t cn = p.chunk_nodes > 0 ? p.chunk_nodes : p.n;
     const int64_t first = c * cn;
     if (first >= p.n) return;
     const int64_t last = first + cn < p.n ? first + cn : p.n;
-    const int cyc = p.W + 1;
-    int32_t refc[kMaxWindowBig + 1 > 128 ? 128 : kMaxWindowBig + 1];       // chain length of the last W+1 nodes (window <= 127 here)
-    for (int i = 0; i < cyc; i++) refc[i] = 0;
+    for (int i = (int)lane; i < cyc; i += 64) refc[i] = 0;
     const int64_t max_ref = p.max_ref < 0 ? (int64_t)0x7FFFFFFF : p.max_ref;
-    for (int64_t x = first; x < last; x++) {
-        const int64_t d = (int64_t)(adj_off[x + 1] - adj_off[x]);
-        uint64_t bits = len_coded((uint64_t)d, p.outdegree_coding, 0);
-        int b = 0;
-        const int ci = (int)((x - first) % cyc);
-        if (d > 0) {
-            uint32_t bv = 0xFFFFFFFFu; int bc = -1;
-            refc[ci] = -1;
-            for (int r = 0; r < cyc; r++) {
-                if (x - r < first && r != 0) break;
-                const int cand = (int)(((x - first) - r + 2ll * cyc) % cyc);
-                const uint32_t sz = sizes[x * cyc + r];
-                if (refc[cand] < max_ref && sz != 0xFFFFFFFFu && sz < bv) { bv = sz; b = r; bc = cand; }
-            }
-            refc[ci] = refc[bc] + 1;
-            bits += bv;
-        } else refc[ci] = 0;                                              // (an empty list is never referenced; its slot just leaves the window)
-        best[x] = (uint8_t)b;
-        recbits[x] = (int32_t)bits;
+    for (int64_t x0 = first; x0 < last; x0 += 64) {
+        const int cntn = (int)(last - x0 < 64 ? last - x0 : 64);
+        __syncthreads();
+        for (int t = (int)lane; t < cntn * cyc; t += 64) tile[t] = sizes[x0 * cyc + t];
+        if ((int)lane < cntn) dl[lane] = (uint32_t)(adj_off[x0 + lane + 1] - adj_off[x0 + lane]);
+        __syncthreads();
+        for (int i = 0; i < cntn; i++) {
+            const int64_t x = x0 + i;
+            const uint32_t d = dl[i];
+            const int ci = (int)((x - first) % cyc);
+            uint32_t bits = (uint32_t)len_coded((uint64_t)d, p.outdegree_coding, 0);
+            uint32_t b = 0;
+            if (d > 0) {
+                if (lane == 0) refc[ci] = -1;                              // (the list itself: "no reference" is always admissible)
+                __syncthreads();
+                unsigned long long key = ~0ull; int kc = -1;
+                for (int r = (int)lane; r < cyc; r += 64) {
+                    if (x - r < first && r != 0) break;
+                    const int cand = (int)(((x - first) - r + 2ll * cyc) % cyc);
+                    const uint32_t sz = tile[i * cyc + r];
+                    const unsigned long long k = ((unsigned long long)sz << 8) | (unsigned)r;
+                    if (refc[cand] < max_ref && sz != 0xFFFFFFFFu && k < key) { key = k; kc = cand; }
+                }
+                unsigned long long m = key;                                 // wave minimum: the smallest size, the nearest reference on a tie
+                for (int o = 32; o >= 1; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t < m ? t : m; }
+                b = (uint32_t)(m & 0xFFu);
+                bits += (uint32_t)(m >> 8);
+                __syncthreads();
+                if (key == m && kc >= 0) refc[ci] = refc[kc] + 1;           // (exactly one lane holds the winner: keys differ in r)
+            } else if (lane == 0) refc[ci] = 0;                            // (an empty list is never referenced; its slot just leaves the window)
+            if (lane == 0) { bl[i] = b; rb[i] = bits; }
+            __syncthreads();
+        }
+        if ((int)lane < cntn) { best[x0 + lane] = (uint8_t)bl[lane]; recbits[x0 + lane] = (int32_t)rb[lane]; }
     }
 }
 
@@ -266,7 +292,7 @@ int encode_store_dev(const bvg_params& bp, const uint64_t* d_adj_off, const int6
         hipLaunchKernelGGL(enc_sizes_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, p, d_adj_off, d_adj, sizes);
         const int64_t cn = p.chunk_nodes > 0 ? p.chunk_nodes : n;
         const int64_t nchunks = (n + cn - 1) / cn;
-        hipLaunchKernelGGL(enc_choose_kernel, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, s, p, d_adj_off, sizes, best, recbits);
+        hipLaunchKernelGGL(enc_choose_kernel, dim3((unsigned)nchunks), dim3(64), (size_t)(64 * cyc + cyc + 3 * 64) * sizeof(uint32_t), s, p, d_adj_off, sizes, best, recbits);
         launch_exclusive_scan(recbits, offsets, n, tmp, s);
         ENC_CHK(hipMemcpyAsync(&total_bits, offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         ENC_CHK(hipStreamSynchronize(s));
