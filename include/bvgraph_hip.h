@@ -186,7 +186,7 @@ int bvg_symmetrize_dev(bvg_graph* g, void* d_soffsets, void* d_ssucc, uint64_t s
  * labels per node (:565-582).  Built for the scalar label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64) and
  * FixedWidthIntLabel (FixedWidthIntLabel.java:70-73), and for FixedWidthIntListLabel (FixedWidthIntListLabel.java:73-78:
  * gamma length + elements of `width` bits per arc); FixedWidthLongListLabel and user classes return BVG_E_UNSUPPORTED. */
-enum { BVG_LABEL_GAMMA_INT = 1, BVG_LABEL_FIXED_INT = 2, BVG_LABEL_FIXED_INT_LIST = 3 };
+enum { BVG_LABEL_GAMMA_INT = 1, BVG_LABEL_FIXED_INT = 2, BVG_LABEL_FIXED_INT_LIST = 3, BVG_LABEL_FIXED_LONG_LIST = 4 };
 typedef struct bvg_labels bvg_labels;
 /* Label.toSpec() text, e.g. "it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,10)" -> kind, width. */
 int bvg_labels_parse_spec(const char* spec, int* kind, int* width);
@@ -209,6 +209,9 @@ int bvg_labels_decode_range(bvg_labels* l, int64_t from, int64_t to, const int32
  * successor order, values[cap] = the concatenated elements; *n_values = their number.  BVG_E_CAPACITY if cap is smaller (list_off is
  * filled either way: size the buffer from list_off[arcs] and call again). */
 int bvg_labels_decode_range_lists(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int32_t* values, uint64_t cap, uint64_t* n_values);
+/* The same for FixedWidthLongListLabel (labelling/FixedWidthLongListLabel.java:81-87: gamma(length), then readLong(width), width <= 64):
+ * kind BVG_LABEL_FIXED_LONG_LIST, 64-bit elements. */
+int bvg_labels_decode_range_lists64(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int64_t* values, uint64_t cap, uint64_t* n_values);
 /* Same as bvg_labels_decode_range, outdegrees (int32) and labels (int32) in device memory: chains with bvg_decode_range_dev without leaving HBM. */
 int bvg_labels_decode_range_dev(bvg_labels* l, int64_t from, int64_t to, const void* d_outdeg, void* d_labels, uint64_t cap, uint64_t* n_labels);
 

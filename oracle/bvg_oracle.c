@@ -832,6 +832,33 @@ int bvgo_labels_decode_lists(int width, const uint8_t* stream, uint64_t nbytes, 
     return values && k > cap ? BVGO_E_ARG : 0;
 }
 
+/* FixedWidthLongListLabel.fromBitStream (labelling/FixedWidthLongListLabel.java:81-87): gamma(length), then `length` readLong(width),
+ * width <= 64.  Test infrastructure like the rest of this file. */
+int bvgo_labels_decode_lists64(int width, const uint8_t* stream, uint64_t nbytes, const uint64_t* loffsets, int64_t nodes,
+                               int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int64_t* values, uint64_t cap, uint64_t* n_values) {
+    if (from < 0 || to < from || to > nodes || !loffsets || !list_off || width < 0 || width > 64) return BVGO_E_ARG;
+    uint64_t a = 0, k = 0;
+    list_off[0] = 0;
+    for (int64_t x = from; x < to; x++) {
+        bvgo_bits b; bvgo_bits_init(&b, stream, nbytes, loffsets[x]);
+        for (int32_t j = 0; j < outdeg[x - from]; j++) {
+            uint64_t len = bvgo_read_gamma(&b);
+            if (b.err) return b.err;
+            for (uint64_t t = 0; t < len; t++) {
+                uint64_t v = 0;
+                if (width > 32) { v = bvgo_read_bits(&b, width - 32) << 32; v |= bvgo_read_bits(&b, 32); } else v = bvgo_read_bits(&b, width);
+                if (b.err) return b.err;
+                if (values && k < cap) values[k] = (int64_t)v;
+                k++;
+            }
+            list_off[++a] = k;
+        }
+        if (b.pos != loffsets[x + 1]) return BVGO_E_EOF;
+    }
+    if (n_values) *n_values = k;
+    return values && k > cap ? BVGO_E_ARG : 0;
+}
+
 int bvgo_labels_decode(int kind, int width, const uint8_t* stream, uint64_t nbytes, const uint64_t* loffsets, int64_t nodes,
                        int64_t from, int64_t to, const int32_t* outdeg, int32_t* out, uint64_t cap, uint64_t* n_out) {
     if (from < 0 || to < from || to > nodes || !loffsets) return BVGO_E_ARG;

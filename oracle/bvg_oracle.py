@@ -78,6 +78,7 @@ def lib():
         L.bvgo_parse_label_spec.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bvgo_labels_decode.argtypes = [C.c_int, C.c_int, vp, u64, vp, i64, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvgo_labels_decode_lists.argtypes = [C.c_int, vp, u64, vp, i64, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
+        L.bvgo_labels_decode_lists64.argtypes = [C.c_int, vp, u64, vp, i64, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -268,4 +269,20 @@ def labels_decode_lists(width, stream, loffsets, frm, to, outdeg):
     _chk(lib().bvgo_labels_decode_lists(*args, None, 0, C.byref(n)))
     vals = np.empty(max(n.value, 1), dtype=np.int32)
     _chk(lib().bvgo_labels_decode_lists(*args, vals.ctypes.data, n.value, C.byref(n)))
+    return loff, vals[:n.value]
+
+
+def labels_decode_long_lists(width, stream, loffsets, frm, to, outdeg):
+    """Long list labels (FixedWidthLongListLabel.java:81-87) of the arcs of nodes [frm,to): (list_off uint64[arcs+1], values int64)."""
+    stream = np.ascontiguousarray(np.frombuffer(bytes(stream), dtype=np.uint8))
+    pad = np.concatenate([stream, np.zeros(16, np.uint8)])
+    lo = np.ascontiguousarray(loffsets, dtype=np.uint64)
+    deg = np.ascontiguousarray(outdeg, dtype=np.int32)
+    arcs = int(deg.sum())
+    loff = np.zeros(arcs + 1, dtype=np.uint64)
+    n = C.c_uint64()
+    args = (width, pad.ctypes.data, len(stream), lo.ctypes.data, len(lo) - 1, frm, to, deg.ctypes.data if len(deg) else None, loff.ctypes.data)
+    _chk(lib().bvgo_labels_decode_lists64(*args, None, 0, C.byref(n)))
+    vals = np.empty(max(n.value, 1), dtype=np.int64)
+    _chk(lib().bvgo_labels_decode_lists64(*args, vals.ctypes.data, n.value, C.byref(n)))
     return loff, vals[:n.value]

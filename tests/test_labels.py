@@ -47,8 +47,9 @@ def test_label_spec_parsers_agree(W, oracle):
                        ("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel( weight , 32 )", (2, 32))):
         assert oracle.parse_label_spec(spec) == want and W.parse_label_spec(spec) == want
     assert W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntListLabel(FOO,10)") == (3, 10) == oracle.parse_label_spec("x.FixedWidthIntListLabel(FOO,10)")
+    assert W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthLongListLabel(FOO,40)") == (4, 40)
     with pytest.raises(W.UnsupportedOperationException):
-        W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthLongListLabel(FOO,40)")
+        W.parse_label_spec("org.example.MyOwnLabel(FOO,40)")
     with pytest.raises(W.IOException):
         W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,33)")
 
@@ -221,3 +222,62 @@ def test_gpu_list_labels_on_a_synthetic_graph(W, tools, oracle):
     with pytest.raises(W.UnsupportedOperationException):
         lg.decode_range(0, n)                                                 # scalar entry point on a list-labelled graph
     lg.close(); g.close()
+
+
+# ---- FixedWidthLongListLabel (labelling/FixedWidthLongListLabel.java:81-95): gamma(length) + readLong(width), width <= 64.  The
+# reference's labelled test builds no graph with it, so the cases are the list cases above with 64-bit elements (parity unpinned by a
+# reference vector, like the int lists; the three restatements -- tooling writer, oracle, HIP -- are written independently).
+LONG_WIDTHS = (0, 1, 31, 32, 33, 47, 63, 64)
+
+
+def _long_list_labels(lists, width):
+    arc_off = np.zeros(len(lists) + 1, dtype=np.uint64)
+    arc_off[1:] = np.cumsum([len(l) for l in lists]) if lists else 0
+    mask = (1 << width) - 1
+    lens = [(j % 5) for l in lists for j in l]                                  # empty lists included
+    loff = np.zeros(len(lens) + 1, dtype=np.uint64)
+    loff[1:] = np.cumsum(lens) if lens else 0
+    vals = np.array([((0x9E3779B97F4A7C15 * (i * 131 + j * 7 + k + 1)) & 0xFFFFFFFFFFFFFFFF) & mask for i, l in enumerate(lists) for j in l for k in range(j % 5)], dtype=np.uint64).astype(np.int64)
+    return arc_off, vals, loff
+
+
+@pytest.mark.parametrize("fam", [0, 2])
+def test_oracle_long_list_labels(tools, oracle, fam):
+    for n in (1, 2, 9, 33):
+        lists = _family(n, fam)
+        for width in LONG_WIDTHS:
+            arc_off, vals, loff = _long_list_labels(lists, width)
+            sl = tools.store_label_long_lists(width, loff, vals, arc_off)
+            deg = np.diff(arc_off.astype(np.int64)).astype(np.int32)
+            lo, got = oracle.labels_decode_long_lists(width, sl.stream, sl.offsets, 0, n, deg)
+            assert np.array_equal(lo, loff) and np.array_equal(got, vals), (n, fam, width)
+            # the stream is what the class writes: gamma(length) then `width` bits per element
+            bits = sum(2 * (int(l) + 1).bit_length() - 1 + int(l) * width for l in np.diff(loff.astype(np.int64)))
+            assert int(sl.offsets[-1]) == bits
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fam", [0, 2])
+def test_gpu_long_list_labels(W, tools, oracle, fam):
+    for n in (1, 2, 9, 33):
+        lists = _family(n, fam)
+        st = tools.store(lists)
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+        for width in LONG_WIDTHS:
+            arc_off, vals, loff = _long_list_labels(lists, width)
+            sl = tools.store_label_long_lists(width, loff, vals, arc_off)
+            lg = W.BitStreamArcLabelledImmutableGraph.from_memory(g, sl.kind, sl.width, sl.stream, sl.offsets)
+            deg, succ, lo, lv = lg.decode_range_lists(0, n)
+            assert lv.dtype == np.int64 and np.array_equal(lo, loff) and np.array_equal(lv, vals), (n, fam, width)
+            for x in range(n):
+                d1, s1, lo1, lv1 = lg.decode_range_lists(x, x + 1)
+                a, b = int(arc_off[x]), int(arc_off[x + 1])
+                assert np.array_equal(lv1, vals[int(loff[a]):int(loff[b])]) and np.array_equal(lo1, loff[a:b + 1] - loff[a])
+        g.close()
+
+
+def test_long_list_label_spec(W):
+    k, w = W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthLongListLabel(FOO,47)")
+    assert (k, w) == (W.LABEL_FIXED_LONG_LIST, 47)
+    with pytest.raises(Exception):
+        W.parse_label_spec("it.unimi.dsi.big.webgraph.labelling.FixedWidthLongListLabel(FOO,65)")

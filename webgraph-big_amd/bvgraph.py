@@ -136,6 +136,7 @@ def lib():
         L.bvg_labels_decode_range.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_labels_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_labels_decode_range_lists.argtypes = [vp, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_labels_decode_range_lists64.argtypes = [vp, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_tile.argtypes = [vp, i64, pp]
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
@@ -698,7 +699,7 @@ def scan_multi(graphs, balance=BALANCE_ARCS):
     return tot.as_dict(), [p.as_dict() for p in per]
 
 
-LABEL_GAMMA_INT, LABEL_FIXED_INT, LABEL_FIXED_INT_LIST = 1, 2, 3
+LABEL_GAMMA_INT, LABEL_FIXED_INT, LABEL_FIXED_INT_LIST, LABEL_FIXED_LONG_LIST = 1, 2, 3, 4
 
 
 def parse_label_spec(spec):
@@ -781,17 +782,20 @@ class BitStreamArcLabelledImmutableGraph:
         return deg, succ, lab[:len(succ)]
 
     def decode_range_lists(self, frm, to):
-        """List labels (FixedWidthIntListLabel): (outdeg, successors, list_off[arcs+1], values)."""
+        """List labels (FixedWidthIntListLabel: int32 values; FixedWidthLongListLabel: int64): (outdeg, successors, list_off[arcs+1], values)."""
         deg, succ = self.g.decode_range(frm, to)
         d32 = np.ascontiguousarray(deg, dtype=np.int32)
         loff = np.zeros(len(succ) + 1, dtype=np.uint64)
         n = C.c_uint64()
-        st = lib().bvg_labels_decode_range_lists(self._h, frm, to, d32.ctypes.data if len(d32) else None, loff.ctypes.data, None, 0, C.byref(n))
+        kind = C.c_int(); width = C.c_int(); nn = C.c_int64(); sb = C.c_uint64()
+        _check(lib().bvg_labels_info(self._h, C.byref(kind), C.byref(width), C.byref(nn), C.byref(sb)), "labels_info")
+        fn, dt = (lib().bvg_labels_decode_range_lists64, np.int64) if kind.value == LABEL_FIXED_LONG_LIST else (lib().bvg_labels_decode_range_lists, np.int32)
+        st = fn(self._h, frm, to, d32.ctypes.data if len(d32) else None, loff.ctypes.data, None, 0, C.byref(n))
         if st != _abi.E_CAPACITY:
             _check(st, "label lists(%d,%d)" % (frm, to))
-        vals = np.empty(max(n.value, 1), dtype=np.int32)
+        vals = np.empty(max(n.value, 1), dtype=dt)
         if n.value:
-            _check(lib().bvg_labels_decode_range_lists(self._h, frm, to, d32.ctypes.data, loff.ctypes.data, vals.ctypes.data, n.value, C.byref(n)), "label lists(%d,%d)" % (frm, to))
+            _check(fn(self._h, frm, to, d32.ctypes.data, loff.ctypes.data, vals.ctypes.data, n.value, C.byref(n)), "label lists(%d,%d)" % (frm, to))
         return deg, succ, loff, vals[:n.value]
 
     def successors(self, x):

@@ -7,7 +7,8 @@
 // nextLong() (:565-582, label.fromBitStream), the random-access iterator positions the stream at offset[x] (:208-229).
 // Label classes handled on the device: GammaCodedIntLabel (one gamma-coded natural per arc, GammaCodedIntLabel.java:60-64) and
 // FixedWidthIntLabel (readInt(width), FixedWidthIntLabel.java:70-73), and the list label FixedWidthIntListLabel (gamma length +
-// elements of `width` bits, FixedWidthIntListLabel.java:73-78) in two passes (lengths, prefix sum, elements).  FixedWidthLongListLabel is not built.
+// elements of `width` bits, FixedWidthIntListLabel.java:73-78) and FixedWidthLongListLabel (the same with readLong(width), width <= 64,
+// FixedWidthLongListLabel.java:81-87) in two passes (lengths, prefix sum, elements).
 //
 // Layout in HBM: the label stream verbatim (zero-padded to 16 bytes + 16), uint64 label_offsets[n+1].  One thread decodes the
 // labels of one node through the generic BitCursor of bvg_device.h and writes them at the node's arc offset (exclusive
@@ -65,9 +66,11 @@ __global__ void __launch_bounds__(256) labels_kernel(const uint8_t* stream, uint
 
 // FixedWidthIntListLabel (FixedWidthIntListLabel.java:73-78): per arc gamma(length) then `length` elements of `width` bits.
 // PASS 0 writes the length of every arc's list (lens[arc]); PASS 1 writes the elements at vals + voff[arc].
-template <int PASS>
+// V = int32_t: FixedWidthIntListLabel (width <= 32); V = int64_t: FixedWidthLongListLabel (readLong(width), width <= 64,
+// FixedWidthLongListLabel.java:81-87).
+template <int PASS, typename V>
 __global__ void __launch_bounds__(256) label_lists_kernel(const uint8_t* stream, uint64_t limit_byte, const uint64_t* loff, int64_t from, int64_t count,
-                                                          const int32_t* deg, const uint64_t* cum, int width, int32_t* lens, const uint64_t* voff, int32_t* vals, unsigned* err) {
+                                                          const int32_t* deg, const uint64_t* cum, int width, int32_t* lens, const uint64_t* voff, V* vals, unsigned* err) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int64_t x = from + i;
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(256) label_lists_kernel(const uint8_t* stream,
         const uint64_t len = c.read_gamma(end);
         if (len > 0x7FFFFFFFull || c.pos + len * (uint64_t)width > end) { e |= ERR_OVERRUN; if (PASS == 0) for (uint32_t t = j; t < d; t++) lens[a0 + t] = 0; break; }
         if (PASS == 0) { lens[a0 + j] = (int32_t)len; c.pos += len * (uint64_t)width; }
-        else { int32_t* const o = vals + voff[a0 + j]; for (uint64_t t = 0; t < len; t++) o[t] = (int32_t)(uint32_t)c.read_bits((unsigned)width); }
+        else { V* const o = vals + voff[a0 + j]; for (uint64_t t = 0; t < len; t++) o[t] = sizeof(V) == 4 ? (V)(int32_t)(uint32_t)c.read_bits((unsigned)width) : (V)c.read_bits((unsigned)width); }
     }
     if (!e && c.pos != end) e |= ERR_MALFORMED;
     if (e) atomicOr(err, e);
@@ -107,6 +110,46 @@ std::string trim(const std::string& s) {
 }  // namespace bvg
 
 using namespace bvg;
+
+template <typename V> int labels_lists_impl(bvg_labels* l, int want_kind, int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, V* values, uint64_t cap, uint64_t* n_values) {
+    if (!l || from < 0 || to < from || to > l->nodes || (to > from && !outdeg) || !list_off) return BVG_E_ARG;
+    if (l->kind != want_kind) return BVG_E_UNSUPPORTED;
+    LCHK(hipSetDevice(l->device));
+    const int64_t cnt = to - from;
+    if (n_values) *n_values = 0;
+    list_off[0] = 0;
+    if (cnt == 0) return 0;
+    uint64_t arcs = 0;
+    for (int64_t i = 0; i < cnt; i++) { if (outdeg[i] < 0) return BVG_E_ARG; arcs += (uint64_t)outdeg[i]; }
+    if (arcs == 0) return 0;
+    int32_t* d_deg = nullptr; int32_t* d_lens = nullptr; V* d_vals = nullptr; uint64_t* d_cum = nullptr; uint64_t* d_voff = nullptr; uint64_t* d_tmp = nullptr;
+    auto done = [&](int code) { for (void* p : {(void*)d_deg, (void*)d_lens, (void*)d_vals, (void*)d_cum, (void*)d_voff, (void*)d_tmp}) if (p) (void)hipFree(p); return code; };
+    const size_t tneed = std::max(scan_tmp_elems(cnt), scan_tmp_elems((int64_t)arcs));
+    if (hipMalloc(&d_deg, (size_t)cnt * 4) != hipSuccess || hipMalloc(&d_cum, (size_t)(cnt + 1) * 8) != hipSuccess || hipMalloc(&d_lens, (size_t)arcs * 4) != hipSuccess ||
+        hipMalloc(&d_voff, (size_t)(arcs + 1) * 8) != hipSuccess || hipMalloc(&d_tmp, tneed * 8) != hipSuccess) return done(BVG_E_NOMEM);
+    if (hipMemcpy(d_deg, outdeg, (size_t)cnt * 4, hipMemcpyHostToDevice) != hipSuccess) return done(BVG_E_HIP);
+    launch_exclusive_scan(d_deg, d_cum, cnt, d_tmp, l->stream);
+    if (hipMemsetAsync(l->d_err, 0, sizeof(unsigned), l->stream) != hipSuccess) return done(BVG_E_HIP);
+    const uint64_t limit = l->padded - 16;
+    const dim3 grid((unsigned)((cnt + 255) / 256));
+    hipLaunchKernelGGL((label_lists_kernel<0, V>), grid, dim3(256), 0, l->stream, l->d_stream, limit, l->d_offsets, from, cnt, d_deg, d_cum, l->width, d_lens, (const uint64_t*)nullptr, (V*)nullptr, l->d_err);
+    launch_exclusive_scan(d_lens, d_voff, (int64_t)arcs, d_tmp, l->stream);
+    unsigned herr = 0;
+    if (hipMemcpyAsync(&herr, l->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (hipMemcpyAsync(list_off, d_voff, (size_t)(arcs + 1) * 8, hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (hipStreamSynchronize(l->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (herr) return done(BVG_E_EOF);
+    const uint64_t total = list_off[arcs];
+    if (n_values) *n_values = total;
+    if (total > cap || (total && !values)) return done(BVG_E_CAPACITY);
+    if (total == 0) return done(0);
+    if (hipMalloc(&d_vals, (size_t)total * sizeof(V)) != hipSuccess) return done(BVG_E_NOMEM);
+    hipLaunchKernelGGL((label_lists_kernel<1, V>), grid, dim3(256), 0, l->stream, l->d_stream, limit, l->d_offsets, from, cnt, d_deg, d_cum, l->width, (int32_t*)nullptr, d_voff, d_vals, l->d_err);
+    if (hipMemcpyAsync(values, d_vals, (size_t)total * sizeof(V), hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (hipMemcpyAsync(&herr, l->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
+    if (hipStreamSynchronize(l->stream) != hipSuccess) return done(BVG_E_HIP);
+    return done(herr ? BVG_E_EOF : 0);
+}
 
 extern "C" {
 
@@ -138,13 +181,21 @@ int bvg_labels_parse_spec(const char* spec, int* kind, int* width) {
         if (endp == w.c_str() || v < 0 || v > 32) return BVG_E_IO;
         *kind = BVG_LABEL_FIXED_INT_LIST; *width = (int)v; return 0;
     }
-    return BVG_E_UNSUPPORTED;                                                 // long lists and user classes
+    if (cls == "FixedWidthLongListLabel") {
+        const size_t comma = args.find(',');
+        if (comma == std::string::npos) return BVG_E_IO;
+        const std::string w = trim(args.substr(comma + 1));
+        char* endp = nullptr; const long v = strtol(w.c_str(), &endp, 10);
+        if (endp == w.c_str() || v < 0 || v > 64) return BVG_E_IO;            // FixedWidthLongListLabel.java:50 (width in [0..64])
+        *kind = BVG_LABEL_FIXED_LONG_LIST; *width = (int)v; return 0;
+    }
+    return BVG_E_UNSUPPORTED;                                                 // user classes
 }
 
 int bvg_labels_open_mem(int kind, int width, int64_t nodes, const uint8_t* stream, uint64_t nbytes, const uint64_t* label_offsets, int device, bvg_labels** out) {
     if (!out || nodes < 0 || !label_offsets || (nbytes && !stream)) return BVG_E_ARG;
-    if (kind != BVG_LABEL_GAMMA_INT && kind != BVG_LABEL_FIXED_INT && kind != BVG_LABEL_FIXED_INT_LIST) return BVG_E_UNSUPPORTED;
-    if (kind != BVG_LABEL_GAMMA_INT && (width < 0 || width > 32)) return BVG_E_ARG;
+    if (kind != BVG_LABEL_GAMMA_INT && kind != BVG_LABEL_FIXED_INT && kind != BVG_LABEL_FIXED_INT_LIST && kind != BVG_LABEL_FIXED_LONG_LIST) return BVG_E_UNSUPPORTED;
+    if (kind != BVG_LABEL_GAMMA_INT && (width < 0 || width > (kind == BVG_LABEL_FIXED_LONG_LIST ? 64 : 32))) return BVG_E_ARG;
     if (label_offsets[nodes] > nbytes * 8) return BVG_E_EOF;
     for (int64_t i = 0; i < nodes; i++) if (label_offsets[i] > label_offsets[i + 1]) return BVG_E_IO;
     int ndev = 0;
@@ -235,7 +286,7 @@ int bvg_labels_info(const bvg_labels* l, int* kind, int* width, int64_t* nodes, 
 // -> d_labels (int32, device).  *n_labels = sum of the outdegrees; BVG_E_CAPACITY if cap is smaller (nothing is written).
 int bvg_labels_decode_range_dev(bvg_labels* l, int64_t from, int64_t to, const void* d_outdeg, void* d_labels, uint64_t cap, uint64_t* n_labels) {
     if (!l || from < 0 || to < from || to > l->nodes || (to > from && !d_outdeg)) return BVG_E_ARG;
-    if (l->kind == BVG_LABEL_FIXED_INT_LIST) return BVG_E_UNSUPPORTED;        // use bvg_labels_decode_range_lists
+    if (l->kind == BVG_LABEL_FIXED_INT_LIST || l->kind == BVG_LABEL_FIXED_LONG_LIST) return BVG_E_UNSUPPORTED;   // use bvg_labels_decode_range_lists[64]
     LCHK(hipSetDevice(l->device));
     const int64_t cnt = to - from;
     if (n_labels) *n_labels = 0;
@@ -298,43 +349,11 @@ int bvg_labels_decode_range(bvg_labels* l, int64_t from, int64_t to, const int32
 // successor order, values = the concatenated elements.  *n_values = total element count; BVG_E_CAPACITY if cap is smaller (list_off
 // is filled either way, so the caller can size the buffer and call again).  Host buffers.
 int bvg_labels_decode_range_lists(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int32_t* values, uint64_t cap, uint64_t* n_values) {
-    if (!l || from < 0 || to < from || to > l->nodes || (to > from && !outdeg) || !list_off) return BVG_E_ARG;
-    if (l->kind != BVG_LABEL_FIXED_INT_LIST) return BVG_E_UNSUPPORTED;
-    LCHK(hipSetDevice(l->device));
-    const int64_t cnt = to - from;
-    if (n_values) *n_values = 0;
-    list_off[0] = 0;
-    if (cnt == 0) return 0;
-    uint64_t arcs = 0;
-    for (int64_t i = 0; i < cnt; i++) { if (outdeg[i] < 0) return BVG_E_ARG; arcs += (uint64_t)outdeg[i]; }
-    if (arcs == 0) return 0;
-    int32_t* d_deg = nullptr; int32_t* d_lens = nullptr; int32_t* d_vals = nullptr; uint64_t* d_cum = nullptr; uint64_t* d_voff = nullptr; uint64_t* d_tmp = nullptr;
-    auto done = [&](int code) { for (void* p : {(void*)d_deg, (void*)d_lens, (void*)d_vals, (void*)d_cum, (void*)d_voff, (void*)d_tmp}) if (p) (void)hipFree(p); return code; };
-    const size_t tneed = std::max(scan_tmp_elems(cnt), scan_tmp_elems((int64_t)arcs));
-    if (hipMalloc(&d_deg, (size_t)cnt * 4) != hipSuccess || hipMalloc(&d_cum, (size_t)(cnt + 1) * 8) != hipSuccess || hipMalloc(&d_lens, (size_t)arcs * 4) != hipSuccess ||
-        hipMalloc(&d_voff, (size_t)(arcs + 1) * 8) != hipSuccess || hipMalloc(&d_tmp, tneed * 8) != hipSuccess) return done(BVG_E_NOMEM);
-    if (hipMemcpy(d_deg, outdeg, (size_t)cnt * 4, hipMemcpyHostToDevice) != hipSuccess) return done(BVG_E_HIP);
-    launch_exclusive_scan(d_deg, d_cum, cnt, d_tmp, l->stream);
-    if (hipMemsetAsync(l->d_err, 0, sizeof(unsigned), l->stream) != hipSuccess) return done(BVG_E_HIP);
-    const uint64_t limit = l->padded - 16;
-    const dim3 grid((unsigned)((cnt + 255) / 256));
-    hipLaunchKernelGGL((label_lists_kernel<0>), grid, dim3(256), 0, l->stream, l->d_stream, limit, l->d_offsets, from, cnt, d_deg, d_cum, l->width, d_lens, (const uint64_t*)nullptr, (int32_t*)nullptr, l->d_err);
-    launch_exclusive_scan(d_lens, d_voff, (int64_t)arcs, d_tmp, l->stream);
-    unsigned herr = 0;
-    if (hipMemcpyAsync(&herr, l->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
-    if (hipMemcpyAsync(list_off, d_voff, (size_t)(arcs + 1) * 8, hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
-    if (hipStreamSynchronize(l->stream) != hipSuccess) return done(BVG_E_HIP);
-    if (herr) return done(BVG_E_EOF);
-    const uint64_t total = list_off[arcs];
-    if (n_values) *n_values = total;
-    if (total > cap || (total && !values)) return done(BVG_E_CAPACITY);
-    if (total == 0) return done(0);
-    if (hipMalloc(&d_vals, (size_t)total * 4) != hipSuccess) return done(BVG_E_NOMEM);
-    hipLaunchKernelGGL((label_lists_kernel<1>), grid, dim3(256), 0, l->stream, l->d_stream, limit, l->d_offsets, from, cnt, d_deg, d_cum, l->width, (int32_t*)nullptr, d_voff, d_vals, l->d_err);
-    if (hipMemcpyAsync(values, d_vals, (size_t)total * 4, hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
-    if (hipMemcpyAsync(&herr, l->d_err, sizeof(unsigned), hipMemcpyDeviceToHost, l->stream) != hipSuccess) return done(BVG_E_HIP);
-    if (hipStreamSynchronize(l->stream) != hipSuccess) return done(BVG_E_HIP);
-    return done(herr ? BVG_E_EOF : 0);
+    return labels_lists_impl<int32_t>(l, BVG_LABEL_FIXED_INT_LIST, from, to, outdeg, list_off, values, cap, n_values);
+}
+// the same for FixedWidthLongListLabel: 64-bit elements
+int bvg_labels_decode_range_lists64(bvg_labels* l, int64_t from, int64_t to, const int32_t* outdeg, uint64_t* list_off, int64_t* values, uint64_t cap, uint64_t* n_values) {
+    return labels_lists_impl<int64_t>(l, BVG_LABEL_FIXED_LONG_LIST, from, to, outdeg, list_off, values, cap, n_values);
 }
 
 }  // extern "C"

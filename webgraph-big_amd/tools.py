@@ -64,6 +64,7 @@ def lib():
         L.bvgt_encode_values.argtypes = [vp, i64, C.c_int, C.c_int, pp, C.POINTER(u64)]
         L.bvgt_store_labels.argtypes = [C.c_int, C.c_int, vp, vp, i64, pp, C.POINTER(u64), pp]
         L.bvgt_store_label_lists.argtypes = [C.c_int, vp, vp, vp, i64, pp, C.POINTER(u64), pp]
+        L.bvgt_store_label_lists64.argtypes = [C.c_int, vp, vp, vp, i64, pp, C.POINTER(u64), pp]
         L.bvgt_free.argtypes = [vp]
         _LIB = L
     return _LIB
@@ -245,3 +246,16 @@ def store_label_lists(width, list_off, values, arc_off):
     if r:
         raise RuntimeError("bvgt_store_label_lists failed: %d" % r)
     return StoredLabels(3, width, _take(b, nb.value), _take(o, 8 * (n + 1), np.uint64))
+
+
+def store_label_long_lists(width, list_off, values, arc_off):
+    """Writes one long LIST per arc (FixedWidthLongListLabel, width <= 64): list_off[m+1] prefix of the list lengths, values int64."""
+    list_off = np.ascontiguousarray(list_off, dtype=np.uint64); values = np.ascontiguousarray(values, dtype=np.int64)
+    arc_off = np.ascontiguousarray(arc_off, dtype=np.uint64)
+    n = len(arc_off) - 1
+    b = C.c_void_p(); o = C.c_void_p(); nb = C.c_uint64()
+    vbuf = values if len(values) else np.zeros(1, np.int64)
+    r = lib().bvgt_store_label_lists64(width, list_off.ctypes.data, vbuf.ctypes.data, arc_off.ctypes.data, n, C.byref(b), C.byref(nb), C.byref(o))
+    if r:
+        raise RuntimeError("bvgt_store_label_lists64 failed: %d" % r)
+    return StoredLabels(4, width, _take(b, nb.value), _take(o, 8 * (n + 1), np.uint64))

@@ -491,6 +491,32 @@ int bvgt_store_label_lists(int width, const uint64_t* list_off, const int32_t* v
     return 0;
 }
 
+// FixedWidthLongListLabel.toBitStream (labelling/FixedWidthLongListLabel.java:90-95): per arc gamma(length) + writeLong(value, width)
+int bvgt_store_label_lists64(int width, const uint64_t* list_off, const int64_t* values, const uint64_t* arc_off, int64_t n, uint8_t** bytes, uint64_t* nbytes, uint64_t** loffsets) {
+    if (width < 0 || width > 64) return BVG_E_ARG;
+    BitWriter w;
+    *loffsets = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+    if (!*loffsets) return BVG_E_NOMEM;
+    const uint64_t mask = width == 64 ? ~0ULL : ((1ULL << width) - 1);
+    for (int64_t x = 0; x < n; x++) {
+        (*loffsets)[x] = w.nbits;
+        for (uint64_t a = arc_off[x]; a < arc_off[x + 1]; a++) {
+            write_gamma(w, list_off[a + 1] - list_off[a]);
+            if (width > 0) for (uint64_t t = list_off[a]; t < list_off[a + 1]; t++) {
+                const uint64_t v = (uint64_t)values[t] & mask;
+                if (width > 32) { w.put(v >> 32, width - 32); w.put(v & 0xFFFFFFFFull, 32); } else w.put(v, width);
+            }
+        }
+    }
+    (*loffsets)[n] = w.nbits;
+    w.flush();
+    *bytes = (uint8_t*)malloc(w.bytes.size() + 16);
+    if (!*bytes) { free(*loffsets); return BVG_E_NOMEM; }
+    memcpy(*bytes, w.bytes.data(), w.bytes.size()); memset(*bytes + w.bytes.size(), 0, 16);
+    *nbytes = w.bytes.size();
+    return 0;
+}
+
 void bvgt_free(void* p) { free(p); }
 
 }  // extern "C"
