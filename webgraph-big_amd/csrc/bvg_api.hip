@@ -435,13 +435,13 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const int w = atoi(getenv("BVG_WG")); wg_nw = (w == 2 || w == 4) ? w : 0;
         }
     }
-    // the big-LDS classes hold few workgroups per CU: there several wavefronts per pool pay (BVG_WGC=0|2|4 overrides)
+    // the big-LDS classes hold few workgroups per CU: several wavefronts per pool paid there in round 1 (BVG_WGC=2|4|8 selects them)
     int wg_class = 0;
     {
         const Codings& c = a.cod;
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_class = getenv("BVG_WGC") ? atoi(getenv("BVG_WGC")) : 4;   // measured on the 8 GiB eu shape: 258.6 ms (0), 254.9 (2), 254.6 (4)
-        if (wg_class != 2 && wg_class != 4) wg_class = 0;
+        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_class = getenv("BVG_WGC") ? atoi(getenv("BVG_WGC")) : 0;   // round 1 (8 GiB eu): 258.6 ms (0), 254.9 (2), 254.6 (4); end of round 2, after the single-wavefront kernel got the window overlay and the leaf pass (2 GiB eu15 / eu): 53.2 / 53.4 ms (0), 53.3 / 53.8 (2), 54.2 / 54.6 (4), 56.5 / 57.7 (8) -- the workgroup kernel is opt-in again
+        if (wg_class != 2 && wg_class != 4 && wg_class != 8) wg_class = 0;
     }
     // The flow scan kernel as tier 0 (bvg_flow.hip): full scans, default codings, 32-bit successors, windows up to 64.  Its LDS holds
     // only the lists of the window that are really copied from, so it keeps more wavefronts resident than the row kernel.

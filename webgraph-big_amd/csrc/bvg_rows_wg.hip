@@ -554,6 +554,7 @@ void launch_rows_wg_decode(const DecodeArgs& a, uint32_t nblocks, int nw, hipStr
     dim3 grid(nblocks);
     const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * 4 + (size_t)a.lds_stage_words * 4;
     if (nw == 2) hipLaunchKernelGGL((rows_wg_kernel<uint32_t, 2>), grid, dim3(128), dyn, s, a);
+    else if (nw == 8) hipLaunchKernelGGL((rows_wg_kernel<uint32_t, 8>), grid, dim3(512), dyn, s, a);
     else hipLaunchKernelGGL((rows_wg_kernel<uint32_t, 4>), grid, dim3(256), dyn, s, a);
 }
 
