@@ -98,6 +98,20 @@ int main(int argc, char** argv) {
             if (o != lab.size()) { printf("FAIL label count\n"); return 1; }
             printf("LABELS %zu ok\n", o);
         }
+        if (n <= 2000000) {   // BVGraph.store on the device gives back the very file that was loaded (the reference's own fixture in the pytest run)
+            std::vector<int32_t> d; std::vector<int64_t> sc;
+            g->decodeRange(0, n, d, sc);
+            std::vector<uint64_t> off((size_t)n + 1, 0);
+            for (int64_t x = 0; x < n; x++) off[(size_t)x + 1] = off[(size_t)x] + (uint64_t)d[(size_t)x];
+            std::vector<uint8_t> bytes; std::vector<uint64_t> offs;
+            BVGraph::store(g->params(), off, sc, bytes, offs);
+            FILE* f = fopen((std::string(argv[1]) + ".graph").c_str(), "rb");
+            if (!f) { printf("FAIL cannot reopen the .graph file\n"); return 1; }
+            std::vector<uint8_t> file; int c; while ((c = fgetc(f)) != EOF) file.push_back((uint8_t)c);
+            fclose(f);
+            if (file != bytes) { printf("FAIL store: %zu bytes, the file has %zu\n", bytes.size(), file.size()); return 1; }
+            printf("STORE %zu bytes identical\n", bytes.size());
+        }
         printf("OK nodes=%lld arcs=%llu chk=%016llx scan_arcs=%llu scan_chk=%016llx split_arcs=%llu\n", (long long)n, (unsigned long long)arcs,
                (unsigned long long)chk, (unsigned long long)r.arcs, (unsigned long long)r.chk, (unsigned long long)parts);
         return 0;

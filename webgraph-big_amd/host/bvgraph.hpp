@@ -111,6 +111,18 @@ public:
         if (x < 0 || x >= p_.nodes) throw std::invalid_argument("Node index out of range");
         int32_t d; check(bvg_outdegrees(h_, x, x + 1, &d), "outdegree"); return d;
     }
+    const bvg_params& params() const { return p_; }
+    // BVGraph.store on the device (bvg_store; BVG:2404-2457 with chunkNodes > 0, the single-threaded store with 0): the bytes of
+    // basename.graph and the bit offsets (basename.offsets holds their gamma-coded gaps)
+    static void store(const bvg_params& p, const std::vector<uint64_t>& adjOff, const std::vector<int64_t>& adj, std::vector<uint8_t>& graph,
+                      std::vector<uint64_t>& offsets, int64_t chunkNodes = 0, int device = 0) {
+        uint8_t* g = nullptr; uint64_t nb = 0; uint64_t* o = nullptr;
+        const int64_t n = (int64_t)adjOff.size() - 1;
+        static const int64_t none = 0;
+        check(bvg_store(&p, n, adjOff.data(), adj.empty() ? &none : adj.data(), chunkNodes, device, &g, &nb, &o), "store");
+        graph.assign(g, g + nb); offsets.assign(o, o + n + 1);
+        bvg_free(g); bvg_free(o);
+    }
     // decode of [from,to): outdegrees + concatenated successor lists
     void decodeRange(int64_t from, int64_t to, std::vector<int32_t>& deg, std::vector<int64_t>& succ) {
         deg.resize((size_t)(to > from ? to - from : 0));
@@ -182,7 +194,7 @@ inline void NodeIterator::fill(int64_t x) {
 inline NodeIterator NodeIterator::copy(int64_t upperBound) const { return NodeIterator(g_->copy(), curr_ + 1, upperBound, batch_); }
 
 // labelling/BitStreamArcLabelledImmutableGraph.java: an underlying BVGraph plus one int label per arc (GammaCodedIntLabel /
-// FixedWidthIntLabel), both decoded on the device.  decodeRange is one batch of the labelled node iterator (:565-582);
+// FixedWidthIntLabel) and the list labels (FixedWidthIntListLabel, FixedWidthLongListLabel), all decoded on the device.  decodeRange is one batch of the labelled node iterator (:565-582);
 // successors(x) positions at the node's label offset (:208-229).
 class BitStreamArcLabelledImmutableGraph {
     std::shared_ptr<BVGraph> g_; bvg_labels* l_ = nullptr;
@@ -204,6 +216,27 @@ public:
         lab.resize(succ.size());
         uint64_t n = 0;
         check(bvg_labels_decode_range(l_, from, to, deg.data(), lab.data(), lab.size(), &n), "labels_decode_range");
+    }
+    // list labels (FixedWidthIntListLabel.java:73-78, FixedWidthLongListLabel.java:81-87): listOff[arcs + 1] = where each arc's list
+    // starts in `values`
+    void decodeRangeLists(int64_t from, int64_t to, std::vector<int32_t>& deg, std::vector<int64_t>& succ, std::vector<uint64_t>& listOff, std::vector<int64_t>& values) {
+        g_->decodeRange(from, to, deg, succ);
+        listOff.assign(succ.size() + 1, 0);
+        int kind = 0, width = 0; int64_t nodes = 0; uint64_t sb = 0;
+        check(bvg_labels_info(l_, &kind, &width, &nodes, &sb), "labels_info");
+        uint64_t n = 0;
+        if (kind == BVG_LABEL_FIXED_LONG_LIST) {
+            int st = bvg_labels_decode_range_lists64(l_, from, to, deg.data(), listOff.data(), nullptr, 0, &n);
+            if (st != BVG_E_CAPACITY) check(st, "labels_decode_range_lists64");
+            values.resize(n);
+            if (n) check(bvg_labels_decode_range_lists64(l_, from, to, deg.data(), listOff.data(), values.data(), n, &n), "labels_decode_range_lists64");
+        } else {
+            int st = bvg_labels_decode_range_lists(l_, from, to, deg.data(), listOff.data(), nullptr, 0, &n);
+            if (st != BVG_E_CAPACITY) check(st, "labels_decode_range_lists");
+            std::vector<int32_t> v32(n);
+            if (n) check(bvg_labels_decode_range_lists(l_, from, to, deg.data(), listOff.data(), v32.data(), n, &n), "labels_decode_range_lists");
+            values.assign(v32.begin(), v32.end());
+        }
     }
 };
 
