@@ -162,6 +162,13 @@ __global__ void enc_sizes_kernel(EncParams p, const uint64_t* adj_off, const int
     sizes[idx] = out;
 }
 
+// the chunk's one wavefront orders its own LDS traffic (its lanes run in lock step; only the compiler has to be held back)
+__device__ __forceinline__ void enc_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // E2: the sequential choice (BVG:2254-2270), one WAVEFRONT per chunk.  The choice for node x needs the chain lengths of the W nodes
 // before it, so a chunk is a serial walk -- but not a walk against global memory: the size table of 64 nodes at a time is staged in
 // LDS with coalesced loads, lane r weighs reference r (admissible? its size), a wave minimum over {size, r} picks the cheapest with
@@ -198,24 +205,31 @@ __global__ void __launch_bounds__(64) enc_choose_kernel(EncParams p, const uint6
             uint32_t b = 0;
             if (d > 0) {
                 if (lane == 0) refc[ci] = -1;                              // (the list itself: "no reference" is always admissible)
-                __syncthreads();
-                unsigned long long key = ~0ull; int kc = -1;
-                for (int r = (int)lane; r < cyc; r += 64) {
-                    if (x - r < first && r != 0) break;
-                    const int cand = (int)(((x - first) - r + 2ll * cyc) % cyc);
-                    const uint32_t sz = tile[i * cyc + r];
-                    const unsigned long long k = ((unsigned long long)sz << 8) | (unsigned)r;
-                    if (refc[cand] < max_ref && sz != 0xFFFFFFFFu && k < key) { key = k; kc = cand; }
+                enc_wave_sync();
+                // lanes weigh 64 references at a time: the smallest admissible size by a wave minimum (0 - max of the complement), the
+                // nearest reference among its holders by a ballot; further groups of 64 (windows above 63) only win with a smaller size
+                uint32_t bsz = 0xFFFFFFFFu; int br = 0, bcand = ci;
+                for (int r0 = 0; r0 < cyc; r0 += 64) {
+                    const int r = r0 + (int)lane;
+                    uint32_t sz = 0xFFFFFFFFu; int cand = 0;
+                    if (r < cyc && !(x - r < first && r != 0)) {
+                        cand = (int)(((x - first) - r + 2ll * cyc) % cyc);
+                        const uint32_t t = tile[i * cyc + r];
+                        if (refc[cand] < max_ref) sz = t;
+                    }
+                    const uint32_t m = ~wave_max32(~sz);
+                    if (m < bsz) {
+                        const int wl = __ffsll((unsigned long long)ballot(sz == m)) - 1;
+                        bsz = m; br = r0 + wl; bcand = __shfl(cand, wl, 64);
+                    }
                 }
-                unsigned long long m = key;                                 // wave minimum: the smallest size, the nearest reference on a tie
-                for (int o = 32; o >= 1; o >>= 1) { const unsigned long long t = __shfl_xor(m, o, 64); m = t < m ? t : m; }
-                b = (uint32_t)(m & 0xFFu);
-                bits += (uint32_t)(m >> 8);
-                __syncthreads();
-                if (key == m && kc >= 0) refc[ci] = refc[kc] + 1;           // (exactly one lane holds the winner: keys differ in r)
+                b = (uint32_t)br;
+                bits += bsz;
+                enc_wave_sync();
+                if (lane == 0) refc[ci] = refc[bcand] + 1;
             } else if (lane == 0) refc[ci] = 0;                            // (an empty list is never referenced; its slot just leaves the window)
             if (lane == 0) { bl[i] = b; rb[i] = bits; }
-            __syncthreads();
+            enc_wave_sync();
         }
         if ((int)lane < cntn) { best[x0 + lane] = (uint8_t)bl[lane]; recbits[x0 + lane] = (int32_t)rb[lane]; }
     }
