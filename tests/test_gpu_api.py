@@ -387,3 +387,19 @@ def test_offsets_are_derived_by_the_chunk_parallel_walk(W, tools, monkeypatch):
         h = W.BVGraph.from_memory(s2.params, s2.graph, None)
         assert np.array_equal(h.offsets(), s2.offsets), kw
         h.close()
+
+
+def test_random_access_down_a_long_reference_chain(W, tools, oracle):
+    """maxrefcount x window > 64: the chain of successors(x) reaches further back than a request block's halo holds (BVG:1084 recurses as
+    deep as it goes).  Such requests leave the batch and are decoded through the block plan; found by tests/test_gpu_fuzz.py."""
+    n = 400
+    base = [n - 3, n - 2, n - 1]
+    lists = [sorted(set(base + [x % 7, (x * 3) % 11 + 20])) for x in range(n)]          # every list copies most of the one before
+    p = W.default_params(window_size=1, max_ref_count=1000)
+    st = tools.store(lists, p)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    nodes = np.array([n - 1, 200, 0, 65, 66, n - 1], dtype=np.int64)
+    deg, succ = g.successors_batch(nodes)
+    assert deg.tolist() == [len(lists[x]) for x in nodes]
+    assert succ.tolist() == [v for x in nodes for v in lists[x]]
+    g.close()

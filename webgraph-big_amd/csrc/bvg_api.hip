@@ -1209,16 +1209,41 @@ static int bvg_successors_batch_impl(bvg_graph* g, const int64_t* nodes, int64_t
     if (n_succ) *n_succ = total;
     if (outdeg) HIPCHK(hipMemcpy(outdeg, at(o_deg), c * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (total > succ_cap || (!succ && total > 0)) return BVG_E_CAPACITY;
-    for (int64_t i = 0; i < count; i++) if (halo[2 * (size_t)i] == 0xFFFFFFFFu) return BVG_E_UNSUPPORTED;   // reference chain > 64 nodes back
+    // A request whose reference chain reaches more than 64 nodes back (possible with maxrefcount x window > 64) does not fit a
+    // request block's halo: it is taken out of the batch (an empty block) and decoded afterwards through the graph's block plan,
+    // whose blocks are cut so that every chain fits (successors(x) recurses as deep as the chain goes, BVG:1084).
+    std::vector<int64_t> deep;
+    for (int64_t i = 0; i < count; i++) if (halo[2 * (size_t)i] == 0xFFFFFFFFu) deep.push_back(i);
+    std::vector<uint64_t> hcum;
+    if (!deep.empty()) {
+        hcum.resize(c + 1);
+        HIPCHK(hipMemcpy(hcum.data(), at(o_cum), (c + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    auto blank_deep = [&]() -> int {
+        for (int64_t i : deep) {
+            const uint64_t pair[2] = {(uint64_t)nodes[i], (uint64_t)nodes[i]}; const uint32_t hz[2] = {0u, 0u};
+            HIPCHK(hipMemcpy((uint64_t*)at(o_first) + 2 * (size_t)i, pair, sizeof pair, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy((uint32_t*)at(o_halo) + 2 * (size_t)i, hz, sizeof hz, hipMemcpyHostToDevice));
+        }
+        return 0;
+    };
+    rc = blank_deep(); if (rc) return rc;
     if (o_succ + (size_t)(total ? total : 1) * sizeof(int64_t) > g->dr_ws_bytes) {
         rc = dr_ensure(g, o_succ + (size_t)(total ? total : 1) * sizeof(int64_t)); if (rc) return rc;
         rc = prepare(); if (rc) return rc;                                   // the workspace moved: redo the (cheap) preparation in the new one
+        rc = blank_deep(); if (rc) return rc;
     }
     BatchPlan bp{(const uint64_t*)at(o_first), (const uint32_t*)at(o_halo), (const uint64_t*)at(o_mask), (uint32_t)count};
     rc = run_decode(g, 0, sh->p.nodes, true, (const uint64_t*)at(o_cum), (int64_t*)at(o_succ), nullptr, nullptr, &bp);
     if (rc == 0 && total) {
         HIPCHK(hipMemcpyAsync(succ, at(o_succ), (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
+    }
+    for (size_t k = 0; k < deep.size() && rc == 0; k++) {                        // (the range decode reuses the workspace: the batch's results are on the host by now)
+        const int64_t i = deep[k]; const uint64_t want = hcum[(size_t)i + 1] - hcum[(size_t)i];
+        int32_t d1 = 0; uint64_t got = 0; int64_t dummy = 0;
+        rc = decode_range_impl(g, nodes[i], nodes[i] + 1, &d1, want ? succ + hcum[(size_t)i] : &dummy, want ? want : 1, &got, false);
+        if (rc == 0 && got != want) rc = BVG_E_STATE;
     }
     return rc;
 }
