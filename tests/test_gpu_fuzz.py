@@ -44,8 +44,12 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
         for k in ("BVG_GIANT", "BVG_NOSKIP", "BVG_EMIT", "BVG_DBG"):
             monkeypatch.delenv(k, raising=False)
         n = int(rng.choice([1, 70, 900, 6000, 45000]))
-        kw = dict(window_size=int(rng.choice([0, 1, 3, 7, 20])), max_ref_count=int(rng.choice([0, 1, 3, 50])),
+        kw = dict(window_size=int(rng.choice([0, 1, 3, 7, 20, 70])), max_ref_count=int(rng.choice([0, 1, 3, 50, -1])),
                   min_interval_length=int(rng.choice([0, 2, 4, 7])), zeta_k=int(rng.choice([1, 2, 3, 5])))
+        if rng.random() < 0.3:                                                 # non-default codings: the generic field decoders
+            kw.update(outdegree_coding=int(rng.choice([1, 2])), block_coding=int(rng.choice([1, 2, 5])), residual_coding=int(rng.choice([1, 2, 3, 6, 7])),
+                      reference_coding=int(rng.choice([1, 2, 5])), block_count_coding=int(rng.choice([1, 2, 5])))
+            if kw["residual_coding"] == 3: kw["zeta_k"] = int(rng.choice([1, 3, 5, 8]))
         tier = str(rng.choice(["default", "giant", "giant", "tasks", "pipelined", "generic"]))
         env = {"giant": dict(BVG_GIANT="2"), "tasks": dict(BVG_EMIT="1", BVG_DBG="16"), "pipelined": dict(BVG_EMIT="0")}.get(tier, {})
         if rng.random() < 0.3: env["BVG_NOSKIP"] = "1"
@@ -54,9 +58,10 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
         p = W.default_params(**kw)
         st = tools.store((off, adj), p, threads=2)
         g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
-        if tier == "generic": g.set_tuning(force_slow=True)
+        wide = bool(rng.random() < 0.2)                                        # the 64-bit successor kernels on a small graph
+        if tier == "generic" or wide: g.set_tuning(force_slow=tier == "generic", force_wide=wide)
         og = _oracle_graph(oracle, st)
-        what = (case, n, kw, tier, env)
+        what = (case, n, kw, tier, env, wide)
         o = og.scan()
         for _ in range(2):                                                     # the second scan uses the index the first one built
             r = g.scan()
@@ -72,6 +77,7 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
         g.close()
         # the device compressor writes the very bytes the CPU tooling wrote
         chunk = int(rng.choice([0, 64, 1000]))
-        if chunk == 0:
-            gb, go = W.store((off, adj), p)
-            assert np.array_equal(gb, st.graph) and np.array_equal(go, st.offsets), what
+        if kw["window_size"] <= 64:                                            # (the device compressor's window limit is 127; the tooling's chunked form matches BVG:2404-2457)
+            ref = st if chunk == 0 else tools.store((off, adj), p, chunk_nodes=chunk, threads=2)
+            gb, go = W.store((off, adj), p, chunk_nodes=chunk)
+            assert np.array_equal(gb, ref.graph) and np.array_equal(go, ref.offsets), what + (chunk,)
