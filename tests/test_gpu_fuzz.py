@@ -74,6 +74,12 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
         nodes = rng.integers(0, n, min(n, 40)).astype(np.int64)
         bd, bs = g.successors_batch(nodes)
         assert np.array_equal(bs, np.concatenate([adj[int(off[x]):int(off[x + 1])] for x in nodes]) if len(nodes) else bs), what
+        if n <= 6000 and adj.size and rng.random() < 0.5:                      # the transposition feed (Transform.transposeOffline on the device)
+            src = np.repeat(np.arange(n, dtype=np.int64), np.diff(off.astype(np.int64)))
+            order = np.lexsort((src, adj))
+            toff, tsucc = g.transpose()
+            assert np.array_equal(tsucc, src[order]), what
+            assert np.array_equal(toff, np.concatenate([[0], np.cumsum(np.bincount(adj, minlength=n))]).astype(np.uint64)), what
         g.close()
         # the device compressor writes the very bytes the CPU tooling wrote
         chunk = int(rng.choice([0, 64, 1000]))
