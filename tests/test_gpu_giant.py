@@ -120,6 +120,23 @@ def test_graph_with_giant_lists(W, tools, oracle, monkeypatch, noskip):
     g.close()
 
 
+def test_lists_with_more_index_tasks_than_threads(W, tools, oracle):
+    """lists of 120 000 successors, every second one copying 80 % of the one before at random: ~40 000 copy blocks and ~100 000
+    residuals per list, i.e. more than 1 024 index tasks per section (the task loops of the giant kernel go round more than once)"""
+    rng = np.random.default_rng(8)
+    off, adj = _giant_graph(rng, 300000, 4, 120000)
+    st = tools.store((off, adj), threads=4)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    o = _oracle_graph(oracle, st).scan()
+    for it in range(3):
+        r = g.scan()
+        assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), it
+    big = np.flatnonzero(np.diff(off.astype(np.int64)) > 100000)
+    bdeg, bsucc = g.successors_batch(big.astype(np.int64))
+    assert np.array_equal(bsucc, np.concatenate([adj[int(off[x]):int(off[x + 1])] for x in big]))
+    g.close()
+
+
 def test_giant_kernel_is_what_ran(W, tools, oracle, monkeypatch, capfd):
     """BVG_DEBUG names the tiers: the giant blocks are decoded by tier 2a, none is left to the generic kernel."""
     monkeypatch.setenv("BVG_DEBUG", "1")
