@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--target-gib", type=float, default=0.0, help="size of the tiled .graph stream per GPU (0 = the shape's default: 512 tiles for eu15, 8 GiB otherwise)")
     ap.add_argument("--shape", default="eu15", choices=sorted(SHAPES))
     ap.add_argument("--tiles", type=int, default=0, help="explicit number of tiles of the base graph (overrides --target-gib)")
-    ap.add_argument("--allow-wide", action="store_true", help="let the tiled graph pass 2^31 nodes: the 64-bit successor kernels run (dtype u64)")
+    ap.add_argument("--allow-wide", action="store_true", help="let the tiled graph pass 2^31 nodes (still the 32-bit successor kernels: they hold every id below 2^32) and, beyond 2^32 - 256 nodes, run the 64-bit kernels (dtype u64)")
     ap.add_argument("--scaling", default=None, choices=["strong", "weak"], help="N > 1: strong = shards of ONE graph (default), weak = one graph per rank")
     ap.add_argument("--balance", default="arcs", choices=["arcs", "bits", "nodes"])
     ap.add_argument("--block-bits", type=int, default=0)
@@ -155,8 +155,8 @@ def main():
         n0 = st.params.nodes
         nb = rank * n_graph if scaling == "weak" else 0
         j_lo, j_hi = (lo + n0 - 1) // n0, hi // n0                       # whole tiles inside [lo, hi)
-        jb = (1 << 31) // n0                                            # the tiles on either side of node 2^31 (64-bit successor values)
-        for j in sorted({j_lo, (j_lo + j_hi) // 2, j_hi - 1} | ({jb - 1, jb} & set(range(j_lo, j_hi)))) if j_hi > j_lo else []:
+        jb, jb2 = (1 << 31) // n0, (1 << 32) // n0                      # the tiles on either side of nodes 2^31 and 2^32
+        for j in sorted({j_lo, (j_lo + j_hi) // 2, j_hi - 1} | ({jb - 1, jb, jb2 - 1, jb2} & set(range(j_lo, j_hi)))) if j_hi > j_lo else []:
             ro = og.scan(0, n0, node_base=nb + j * n0, threads=threads)
             rg = g.scan(j * n0, (j + 1) * n0)
             assert (rg["arcs"], rg["chk"]) == (ro["arcs"], ro["chk"]), "GPU scan of tile %d disagrees with the CPU oracle" % j
@@ -192,7 +192,7 @@ def main():
         out = {
             "metric": "decoded edges/s, full sequential successor scan", "value": edges_per_s, "unit": "edges/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": steady_s * 1e3,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32" if n_graph < (1 << 31) else "u64",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32" if n_graph <= 0xFFFFFF00 else "u64",
             "data": "synthetic",
             "config": {"workload": wl + (" [stand-in: no LAW dataset on the box]" if args.shape == "eu15" else ""), "shape": args.shape,
                        "nodes": n_graph * (world if scaling == "weak" else 1), "arcs": tot_arcs, "graph_bytes": total_gbytes,
@@ -202,7 +202,7 @@ def main():
                                    + "; RCCL all-reduce of {arcs,chk} only"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
-                         "kernel": "bvg::rows_kernel<%s,scan,tasks> (tier 0) with rows_wg_kernel<u32,4> (big-LDS classes), decode_kernel<slow> (giants) and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream" % ("u32" if n_graph < (1 << 31) else "u64"), "kernel_ms": k_ms,
+                         "kernel": "bvg::rows_kernel<%s,scan,tasks> (tier 0 and, with larger pools, the big-LDS classes), giant_kernel / decode_kernel<slow> for lists too long for LDS and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream" % ("u32" if n_graph <= 0xFFFFFF00 else "u64"), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": gbytes, "index_bytes_per_launch": r["index_bytes"]},
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
             "index_build_s": max(first_scan_s - steady_s, 0.0), "hbm_resident_bytes": int(resident),

@@ -7,7 +7,7 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 O = os.path.join(R, "gpurun_out", "r02_final"); P = os.path.join(R, "profiles")
 cp = lambda a, b: shutil.copy(os.path.join(O, a), os.path.join(P, b))
 for a, b in [("bench_eu15.json", "r02_eu15_bench.json"), ("bench_eu.json", "r02_eu8g_bench.json"), ("bench_web.json", "r02_web8g_bench.json"), ("bench_w0.json", "r02_w08g_bench.json"),
-             ("bench_eu_u64.json", "r02_eu_u64_bench.json"), ("bench_eu15_torchrun1.json", "r02_eu15_torchrun1_bench.json"), ("strong_rehearsal.txt", "r02_strong_rehearsal.txt"),
+             ("bench_eu_2g3.json", "r02_eu_2g3nodes_bench.json"), ("bench_eu_u64.json", "r02_eu_u64_bench.json"), ("bench_eu15_torchrun1.json", "r02_eu15_torchrun1_bench.json"), ("strong_rehearsal.txt", "r02_strong_rehearsal.txt"),
              ("speedtest.json", "r02_speedtest.json"), ("ktrace.txt", "r02_eu15_scan_timeline.txt"), ("pmc_summary.txt", "r02_eu15_pmc_summary.txt"), ("pmc_summary.json", "r02_eu15_pmc.json"),
              ("prof.txt", "r02_section_timers.txt"), ("ldspad.txt", "r02_occupancy_ldspad.txt")]:
     if os.path.exists(os.path.join(O, a)):

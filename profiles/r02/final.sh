@@ -5,7 +5,8 @@ say() { echo "[final] $*"; }
 say "bench lines"
 python bench.py > $O/bench_eu15.json 2> $O/bench_eu15.err; say "eu15 done"
 for sh in eu web w0; do python bench.py --shape $sh --no-cpu-baseline > $O/bench_$sh.json 2> $O/bench_$sh.err; say "$sh done"; done
-python bench.py --shape eu --tiles 1100 --allow-wide --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_eu_u64.json 2> $O/bench_eu_u64.err; say "u64 done"
+python bench.py --shape eu --tiles 1100 --allow-wide --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_eu_2g3.json 2> $O/bench_eu_2g3.err; say "2.3 G nodes done"
+python bench.py --shape eu --tiles 2100 --allow-wide --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_eu_u64.json 2> $O/bench_eu_u64.err; say "u64 (4.4 G nodes) done"
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_torchrun1.log 2>&1; grep '^{' $O/bench_torchrun1.log > $O/bench_eu15_torchrun1.json; say "torchrun 1 rank (RCCL) done"
 bash profiles/r02/strong_rehearsal.sh > $O/strong_rehearsal.txt 2>&1; say "strong rehearsal done"
 python profiles/r02/speedtest.py > $O/speedtest.json 2> $O/speedtest.err; say "speedtest done"

@@ -832,7 +832,9 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
     r = ensure_device(device); if (r) return r;
     Shared* sh = new Shared();
     sh->device = device; sh->p = *p; sh->nbytes = nbytes;
-    sh->wide = p->nodes > (int64_t)0x7FFFFFFF;
+    // 32-bit successor arithmetic holds every node id below 2^32 - 1 (0xFFFFFFFF is the lists' sentinel); the reference's own line between
+    // the int and the long library is 2^31 because Java ints are signed -- nothing here is
+    sh->wide = p->nodes > (int64_t)0xFFFFFF00ll || (getenv("BVG_WIDE_FROM_2_31") != nullptr && p->nodes > (int64_t)0x7FFFFFFF);
     const int64_t n = p->nodes;
     if (d_graph_in) { sh->d_graph = (uint8_t*)d_graph_in; sh->own_graph = false; sh->padded = ((nbytes + 15) & ~15ull) + 16; }
     else {
