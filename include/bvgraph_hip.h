@@ -136,7 +136,7 @@ void bvg_host_free(void* p);
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum).
  * The first scan / decode that covers >= 1/4 of the nodes also builds the residual skip index (two extra passes, once per
- * graph, shared by bvg_copy() flyweights; 8 bytes (12 for >= 2^31 nodes) per 16 residuals of lists with >= 24 residuals;
+ * graph, shared by bvg_copy() flyweights; 6 bytes (10 for graphs on the 64-bit successor kernels: more than 2^32 - 256 nodes) per 16 residuals of lists with >= 24 residuals;
  * BVG_NOSKIP=1 disables). */
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
@@ -235,7 +235,7 @@ int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out);
 /* ---- tuning knobs (optional) ---- */
 typedef struct bvg_tuning {
     uint32_t block_bits;     /* target compressed bits per node block (one wavefront each); 0 = default */
-    uint32_t force_wide;     /* 1 = use the 64-bit successor kernels even when nodes < 2^31 */
+    uint32_t force_wide;     /* 1 = use the 64-bit successor kernels even when every node id fits 32 bits (nodes <= 2^32 - 256) */
     uint32_t force_slow;     /* 1 = route every block through the global-memory slow path (tests) */
     uint32_t reserved;       /* low byte 2 = experimental streaming kernel as tier 0; bits 8.. = its grab threshold */
 } bvg_tuning;
