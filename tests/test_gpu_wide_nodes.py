@@ -9,10 +9,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bits", [31, 32])
-def test_scan_and_decode_past_2_to_31_nodes(W, tools, oracle, bits):
+@pytest.mark.parametrize("bits,wide_from_2_31", [(31, False), (31, True), (32, False)])
+def test_scan_and_decode_past_2_to_31_nodes(W, tools, oracle, monkeypatch, bits, wide_from_2_31):
     """bits = 31: ids and successors in [2^31, 2^32) -- still the 32-bit successor kernels (they hold every id below 2^32 - 1; the
     reference splits at 2^31 only because Java ints are signed); bits = 32: more than 2^32 nodes, the 64-bit kernels on real 64-bit values."""
+    if wide_from_2_31: monkeypatch.setenv("BVG_WIDE_FROM_2_31", "1")           # round 1's switch: the 64-bit kernels on ids in [2^31, 2^32)
     n0 = 1 << 19
     st = tools.synth_store(n0, seed=77, synth=tools.web_like(mean_deg=3.0, p_empty=0.5, max_deg=200), threads=4)
     tiles = (1 << bits) // n0 + 3
