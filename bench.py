@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--cpu-gib", type=float, default=1.0, help="size of the stream the CPU baseline scans")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-tile checksum gate against the CPU oracle")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on a one-GPU box)")
+    ap.add_argument("--echo-ranks", action="store_true", help="plumbing test: every rank prints 'rank r of w' and exits before touching the GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -68,9 +69,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ       # under torch.distributed.run, also with one rank
-    if launched:
-        args.gpus = world
+    if not launched and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD (nothing in this process has
+        # touched the GPU yet, and it never will: it only relays the ranks' output and exit code)
+        sys.exit(self_launch(args.gpus))
+    if launched and world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     scaling = args.scaling or ("strong" if world > 1 else "weak")
+    if args.echo_ranks:
+        print("rank %d of %d" % (rank, world), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -191,7 +199,7 @@ def main():
         steady_s = elapsed / args.steps
         out = {
             "metric": "decoded edges/s, full sequential successor scan", "value": edges_per_s, "unit": "edges/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": steady_s * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": steady_s * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32" if n_graph <= 0xFFFFFF00 else "u64",
             "data": "synthetic",
             "config": {"workload": wl + (" [stand-in: no LAW dataset on the box]" if args.shape == "eu15" else ""), "shape": args.shape,
@@ -217,6 +225,21 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(n):
+    """Runs this very command line under `python -m torch.distributed.run --nproc-per-node n` in a child process and returns its
+    exit code.  Rank 0 of the child prints the JSON line to the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def measured_traffic(shape, tiles, base_nodes, world, scaling):

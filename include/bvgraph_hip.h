@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BVG_ABI_VERSION 1
+#define BVG_ABI_VERSION 2
 
 /* Status codes; each maps 1:1 to the exception class the reference throws at the cited line. */
 typedef enum bvg_status {
@@ -70,6 +70,7 @@ typedef struct bvg_scan_result {
     double kernel_ms;      /* hipEvent time of the scan kernel(s) on the handle's stream */
     uint32_t launches;     /* kernel launches issued (1 + slow-path relaunches) */
     uint32_t slow_blocks;  /* node blocks that had to take the global-memory slow path */
+    uint64_t index_entries; /* residual skip entries of the scanned blocks that an index was present for (0 = the scan ran index-less) */
 } bvg_scan_result;
 
 typedef struct bvg_graph bvg_graph;
@@ -135,10 +136,17 @@ void bvg_host_free(void* p);
  * decoded together with the few earlier nodes its reference chain reaches (the recursion of BVG:1084). */
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum).
- * The first scan / decode that covers >= 1/4 of the nodes also builds the residual skip index (two extra passes, once per
- * graph, shared by bvg_copy() flyweights; 6 bytes (10 for graphs on the 64-bit successor kernels: more than 2^32 - 256 nodes) per 16 residuals of lists with >= 24 residuals;
- * BVG_NOSKIP=1 disables). */
+ * The first scan of >= 4096 nodes also builds the residual skip index of the node blocks it covers (two extra passes; a shard
+ * of a multi-GPU scan therefore indexes its own part only, a later scan of other nodes indexes the whole graph); a materialising
+ * call (bvg_decode_range) builds it for the whole graph once it covers >= 1/4 of the nodes.  The index is shared by bvg_copy()
+ * flyweights: 6 bytes (10 for graphs on the 64-bit successor kernels: more than 2^32 - 256 nodes) per 16 residuals of lists
+ * with >= 24 residuals (cf. the offset cache the reference builds at load, BVG:1545-1558).  The same passes VALIDATE the
+ * blocks: the lean scan kernel then skips the checks a well-formed stream cannot fail, blocks that failed one stay on the
+ * checking kernels for good. */
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
+/* Builds that index for the blocks of [from,to) now (0, nodes = the whole graph) instead of inside the first scan; a no-op when
+ * they are covered already.  entries / bytes (either may be NULL) report what the index of the graph holds afterwards. */
+int bvg_build_index(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, uint64_t* bytes);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
  * IG:405-436; cf. algo/HyperBall.java:748-768): bounds[0..k], bounds[0]=0, bounds[k]=nodes. */
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);

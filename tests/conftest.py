@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the mode-forcing switches of the product library (BVG_EMIT, BVG_DBG, BVG_GIANT, BVG_NOSKIP, ...) are live only in a process
+# that had BVG_TEST_KNOBS set when the library was first used (csrc/bvg_kernels.h: knob())
+os.environ.setdefault("BVG_TEST_KNOBS", "1")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CNR = os.path.join(GOLDEN, "cnr-2000")
 

@@ -88,3 +88,44 @@ def test_copies_with_different_block_sizes_scan_concurrently(W, graph):
         assert out[i] == [want] * 6, i
     for h in hs:
         h.close()
+
+
+def test_every_shard_of_an_8_way_split_scans_with_its_part_of_the_skip_index(W, tools, oracle):
+    """VERDICT r2 / ADVICE r2: a shard smaller than a quarter of the graph used to scan index-less.  Now the first scan of a shard
+    indexes exactly the blocks it covers: 8 shards hold 8 disjoint parts that add up to the whole index, every shard reads
+    skip entries, and the whole-graph scan afterwards still agrees.  (ImmutableGraph.java:405-436, algo/HyperBall.java:748-768)"""
+    from webgraph_big_amd import shard as S
+    st = tools.synth_store(200000, seed=5, synth=tools.eu_like(mean_deg=80.0), threads=4)
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    whole = og.scan()
+    ref = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    e_all, b_all = ref.build_index()
+    assert e_all > 1000 and b_all >= 6 * e_all
+    r_all = ref.scan()
+    assert r_all["index_entries"] == e_all and (r_all["arcs"], r_all["chk"]) == (whole["arcs"], whole["chk"])
+    k = 8
+    bounds = ref.shard_bounds(k, W.BALANCE_ARCS)
+    ent = 0; arcs = 0; chk = 0
+    for r in range(k):
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)      # a replica per rank, as on the 8-GPU node
+        res, a, c = S.sharded_scan(lambda lo, hi: g.scan(lo, hi), bounds, r, reduce=False)
+        assert res["index_entries"] > 0, "shard %d scanned without skip entries" % r
+        e_r, _ = g.build_index(int(bounds[r]), int(bounds[r + 1]))      # covered already: reports what the replica holds
+        assert 0 < e_r < e_all / 4, (r, e_r, e_all)                     # its own part, not the whole index
+        o = og.scan(int(bounds[r]), int(bounds[r + 1]))
+        assert (a, c) == (o["arcs"], o["chk"])
+        ent += res["index_entries"]; arcs += a; chk = (chk + c) % (1 << 64)
+        if r == 3:                                                      # a scan outside the shard re-indexes the whole graph, once
+            rr = g.scan()
+            assert (rr["arcs"], rr["chk"]) == (whole["arcs"], whole["chk"]) and rr["index_entries"] == e_all
+            assert g.scan(int(bounds[r]), int(bounds[r + 1]))["chk"] == c
+        g.close()
+    assert (arcs, chk) == (whole["arcs"], whole["chk"])
+    assert abs(ent - e_all) <= 64 * k                                   # blocks at a seam are indexed by both neighbours
+    ref.close()
+
+
+def test_scan_multi_rejects_one_handle_twice(W, graph):
+    g, og, st = graph
+    with pytest.raises(W.IllegalArgumentException):
+        W.scan_multi([g, g])

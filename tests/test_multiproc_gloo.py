@@ -3,8 +3,8 @@ bench.py calls (shard.sharded_scan / allreduce_scan / allreduce_max):
   * weak scaling: node-range shards with a node-id base; the reduced {arcs, chk} equal those of the whole (tiled) graph;
   * strong scaling: ONE graph, rank r scans [bounds[r], bounds[r+1]) of the arc-balanced split; the reduced pair equals the
     one-piece scan (BASELINE config 5).
-The per-shard scans run on the CPU oracle here (there is no GPU in this container); on the GPU box bench.py hands the same
-helper the HIP handle's scan and the reduction runs over RCCL."""
+The per-shard scans run on the CPU oracle where there is no GPU (this container); where there is one, the strong-scaling half
+hands the helper the HIP handle's scan (two ranks sharing the device), as bench.py does with RCCL in place of gloo."""
 import os
 import socket
 import sys
@@ -35,7 +35,13 @@ def _worker(rank, world, port, n, seed, q):
     # strong: one graph, arc-balanced node ranges (bench.py --scaling strong)
     deg, _ = og.decode_range(0, n)
     bounds = S.bounds_by_arcs(deg, world)
-    own, sarcs, schk = S.sharded_scan(lambda lo, hi: og.scan(lo, hi), bounds, rank)
+    scan = lambda lo, hi: og.scan(lo, hi)
+    import torch
+    if torch.cuda.device_count() > 0:                                    # a GPU box: the product handle does the scanning, gloo the reduction
+        hg = W.BVGraph.from_memory(st.params, st.graph, st.offsets, device=0)
+        assert hg.shard_bounds(world, W.BALANCE_ARCS).tolist() == bounds.tolist()
+        scan = lambda lo, hi: hg.scan(lo, hi)
+    own, sarcs, schk = S.sharded_scan(scan, bounds, rank)
     if rank == 0:
         q.put((arcs, chk, tmax, sarcs, schk, bounds.tolist(), own["arcs"]))
     dist.barrier()

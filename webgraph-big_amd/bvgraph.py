@@ -141,7 +141,8 @@ def lib():
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
         L.bvg_arc_mix.argtypes = [u64, u64]; L.bvg_arc_mix.restype = u64
-        if L.bvg_abi_version() != 1:
+        L.bvg_build_index.argtypes = [vp, i64, i64, C.POINTER(u64), C.POINTER(u64)]
+        if L.bvg_abi_version() != 2:
             raise ImportError("libbvgraph_hip.so ABI mismatch")
         _LIB = L
     return _LIB
@@ -678,6 +679,14 @@ class BVGraph:
             st = lib().bvg_symmetrize(self._h, soff.ctypes.data, ssucc.ctypes.data, len(ssucc), C.byref(need))
         _check(st, "symmetrize")
         return soff, ssucc[:int(need.value)]
+
+    def build_index(self, frm=0, to=None):
+        """Builds the residual skip index (and validates the blocks) of nodes [frm, to) now (bvg_build_index) instead of inside
+        the first scan; returns (entries, bytes) of the graph's index afterwards."""
+        to = self.num_nodes() if to is None else to
+        e = C.c_uint64(); b = C.c_uint64()
+        _check(lib().bvg_build_index(self._h, frm, to, C.byref(e), C.byref(b)), "build_index(%d,%d)" % (frm, to))
+        return int(e.value), int(b.value)
 
     def scan(self, frm=0, to=None):
         """Full sequential successor scan consumed on chip (SpeedTest.java:127-141): dict of bvg_scan_result."""

@@ -30,7 +30,7 @@ using namespace bvg;
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
         if (_e != hipSuccess) {                                                               \
-            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            if (dbg_on()) fprintf(stderr, "[bvg] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
             return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP;                         \
         }                                                                                     \
     } while (0)
@@ -49,6 +49,25 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// Residual skip index of the plan blocks [blk_lo, blk_hi) (a shard builds only its own blocks; everything outside has no entries and
+// is decoded index-less).  Also the record of which blocks a VALIDATING pass of the row kernel has decoded from end to end
+// (fmt[b] == 1): the lean scan kernel (bvg_scan.hip) takes only those.  Immutable once published.
+struct SkipIndex {
+    int device = 0;
+    uint32_t blk_lo = 0, blk_hi = 0;
+    uint64_t total = 0; uint64_t* d_first = nullptr; uint16_t* d_bit = nullptr; void* d_val = nullptr; uint8_t* d_fmt = nullptr;
+    bool wide = false;                        // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
+    std::vector<uint64_t> h_first;            // nblk + 1 entry indices (host copy: index_bytes of a range)
+    SkipIndex() = default; SkipIndex(const SkipIndex&) = delete; SkipIndex& operator=(const SkipIndex&) = delete;
+    ~SkipIndex() {
+        (void)hipSetDevice(device);
+        if (d_first) (void)hipFree(d_first);
+        if (d_bit) (void)hipFree(d_bit);
+        if (d_val) (void)hipFree(d_val);
+        if (d_fmt) (void)hipFree(d_fmt);
+    }
+};
+
 struct Plan {
     uint32_t block_bits = 0;
     uint32_t nblk = 0;
@@ -56,20 +75,11 @@ struct Plan {
     std::vector<uint64_t> h_first;
     std::vector<uint32_t> h_maxd;             // largest (list + the W lists before it) a block decodes: predicts its tier
     uint64_t version = 0;
-    // residual skip index (built by two passes of the row kernel the first time a large range is decoded)
-    std::atomic<int> skip_state{0};           // 0 = not built yet, 1 = built (skip_total may be 0: nothing to index); published with release order
-    uint64_t skip_total = 0; uint64_t* d_skip_first = nullptr; uint16_t* d_skip_bit = nullptr; void* d_skip_val = nullptr; uint8_t* d_skip_fmt = nullptr;
-    bool skip_wide = false;                   // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
-    std::vector<uint64_t> h_skip_first;
-    void release_skip() {
-        if (d_skip_first) (void)hipFree(d_skip_first);
-        if (d_skip_bit) (void)hipFree(d_skip_bit);
-        if (d_skip_val) (void)hipFree(d_skip_val);
-        if (d_skip_fmt) (void)hipFree(d_skip_fmt);
-        d_skip_first = nullptr; d_skip_bit = nullptr; d_skip_val = nullptr; d_skip_fmt = nullptr; skip_total = 0; skip_state.store(0); h_skip_first.clear();
-    }
+    // residual skip index: an immutable snapshot (SkipIndex below), replaced as a whole and read through atomic_load, so a scan
+    // running on another thread keeps the arrays it started with
+    std::shared_ptr<struct SkipIndex> skip;
     void release() {
-        release_skip();
+        std::atomic_store(&skip, std::shared_ptr<struct SkipIndex>());
         if (d_first) (void)hipFree(d_first);
         if (d_halo) (void)hipFree(d_halo);
         if (d_mask) (void)hipFree(d_mask);
@@ -124,6 +134,7 @@ struct bvg_graph {
     void* tr_ws = nullptr; size_t tr_ws_bytes = 0;   // bvg_transpose workspace, kept between calls
     size_t tr_o_cum = 0, tr_o_succ = 0;             // where the last transpose left the graph's own CSR in it (bvg_symmetrize)
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
+    std::shared_ptr<SkipIndex> skip_building;          // transient: the index the fill pass (skip_mode 2) writes
     struct Pred {
         uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
         std::vector<uint8_t> learned; uint64_t learned_version = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
@@ -196,7 +207,7 @@ int make_handle(Shared* sh, bvg_graph** out) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         for (int i = 0; i < bvg_graph::kSide; i++) {
-            HIPCHK(hipStreamCreateWithPriority(&g->side[i], hipStreamNonBlocking, getenv("BVG_PRIO") ? (atoi(getenv("BVG_PRIO")) > 0 ? greatest : atoi(getenv("BVG_PRIO")) < 0 ? least : 0) : greatest));
+            HIPCHK(hipStreamCreateWithPriority(&g->side[i], hipStreamNonBlocking, knob("BVG_PRIO") ? (atoi(knob("BVG_PRIO")) > 0 ? greatest : atoi(knob("BVG_PRIO")) < 0 ? least : 0) : greatest));
             HIPCHK(hipEventCreateWithFlags(&g->side_ev[i], hipEventDisableTiming));
         }
     }
@@ -310,43 +321,51 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                bvg_scan_result* res, const BatchPlan* batch = nullptr, const std::shared_ptr<Plan>* use_plan = nullptr);
 
 // Residual skip index: nodes with long residual lists get one entry per kSkipEvery residuals, so the row kernel can decode a
-// long list as independent segments on otherwise idle lanes.  Two passes of the ordinary decode over the whole graph: count the
-// entries of every block, prefix-sum on the host, fill.  An index, not a cache: every gap is still decoded from the stream.
-int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp) {
+// long list as independent segments on otherwise idle lanes.  Two passes of the ordinary decode over the plan blocks [blo, bhi):
+// count the entries of every block, prefix-sum on the host, fill.  An index, not a cache: every gap is still decoded from the stream.
+// The fill pass is also the VALIDATING pass: a block it decodes from end to end with the position logic (which refuses streams
+// that overlap, counts that contradict each other, ...) is marked fmt = 1, and only such blocks are given to the lean scan kernel.
+// The result replaces the plan's snapshot; scans that hold the old one keep it alive until they return.
+int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uint32_t bhi) {
     Shared* sh = g->sh;
     std::lock_guard<std::mutex> lk(sh->skip_mu);
     Plan& pl = *plp;
-    if (pl.skip_state.load(std::memory_order_acquire)) return 0;
+    {
+        std::shared_ptr<SkipIndex> cur = std::atomic_load(&pl.skip);
+        if (cur && cur->blk_lo <= blo && bhi <= cur->blk_hi) return 0;            // another thread built it meanwhile
+        if (cur) { blo = 0; bhi = pl.nblk; }                                      // a second range: index the whole graph once and for all
+    }
     const uint32_t nblk = pl.nblk;
-    const int64_t n = sh->p.nodes;
-    if (!nblk || n == 0) { pl.skip_state.store(1, std::memory_order_release); return 0; }
+    if (!nblk || sh->p.nodes == 0 || blo >= bhi) return 0;
+    const int64_t nfrom = (int64_t)pl.h_first[blo], nto = (int64_t)pl.h_first[bhi];
     const bool build_wide = sh->wide || g->tun.force_wide;
-    uint32_t* d_cnt = nullptr;
-    HIPCHK(hipMalloc(&d_cnt, (size_t)nblk * sizeof(uint32_t)));
-    HIPCHK(hipMemset(d_cnt, 0, (size_t)nblk * sizeof(uint32_t)));
-    g->skip_mode = 1; g->skip_cnt = d_cnt;
-    int r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
+    std::shared_ptr<SkipIndex> ix = std::make_shared<SkipIndex>();
+    ix->device = sh->device; ix->blk_lo = blo; ix->blk_hi = bhi; ix->wide = build_wide;
+    auto publish = [&]() { std::atomic_store(&pl.skip, ix); return 0; };
+    auto give_up = [&]() { (void)hipGetLastError(); return 0; };                  // no index: the scans run without one
+    DevBuf cnt_d;
+    if (cnt_d.alloc((size_t)nblk * sizeof(uint32_t)) || hipMemset(cnt_d.p, 0, (size_t)nblk * sizeof(uint32_t)) != hipSuccess) return give_up();
+    g->skip_mode = 1; g->skip_cnt = (uint32_t*)cnt_d.p;
+    int r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_cnt = nullptr;
     std::vector<uint32_t> cnt(nblk);
-    if (!r && hipMemcpy(cnt.data(), d_cnt, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
-    (void)hipFree(d_cnt);
-    if (r) { pl.skip_state.store(1, std::memory_order_release); return 0; }                // a bad stream surfaces in the caller's own decode; no index then
+    if (!r && hipMemcpy(cnt.data(), cnt_d.p, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
+    if (r) return give_up();                                                      // a bad stream surfaces in the caller's own decode
     std::vector<uint64_t> first(nblk + 1, 0);
-    for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + cnt[i];
+    for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + ((i >= blo && i < bhi) ? cnt[i] : 0u);
     const uint64_t total = first[nblk];
-    if (total == 0) { pl.skip_state.store(1, std::memory_order_release); return 0; }
-    if (hipMalloc(&pl.d_skip_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&pl.d_skip_bit, total * sizeof(uint16_t) + 16) != hipSuccess || hipMalloc(&pl.d_skip_fmt, nblk) != hipSuccess || hipMemset(pl.d_skip_fmt, 0, nblk) != hipSuccess ||
-        hipMalloc(&pl.d_skip_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); (void)hipGetLastError(); return 0; }
-    if (hipMemcpy(pl.d_skip_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
-    pl.skip_total = total; pl.skip_wide = build_wide;
-    g->skip_mode = 2;
-    r = run_decode(g, 0, n, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
-    g->skip_mode = 0;
-    if (r) { pl.release_skip(); pl.skip_state.store(1, std::memory_order_release); return 0; }
-    pl.h_skip_first.swap(first);
-    pl.skip_state.store(1, std::memory_order_release);
-    if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] residual skip index: %llu entries, %.1f MiB\n", (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0);
-    return 0;
+    if (hipMalloc(&ix->d_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&ix->d_bit, total * sizeof(uint16_t) + 16) != hipSuccess ||
+        hipMalloc(&ix->d_fmt, nblk) != hipSuccess || hipMemset(ix->d_fmt, 0, nblk) != hipSuccess ||
+        hipMalloc(&ix->d_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16) != hipSuccess) return give_up();
+    if (hipMemcpy(ix->d_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return give_up();
+    ix->total = total;
+    g->skip_mode = 2; g->skip_building = ix;
+    r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
+    g->skip_mode = 0; g->skip_building.reset();
+    if (r) return give_up();
+    ix->h_first.swap(first);
+    if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0);
+    return publish();
 }
 
 int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
@@ -358,9 +377,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     std::shared_ptr<Plan> plp = use_plan ? *use_plan : no_plan;                     // held for the whole call (see Shared::plans)
     if (!batch && !use_plan) { r = build_plan(g, block_bits_of(g), plp); if (r) return r; }
     const bool rows_default = (g->tun.reserved & 0xFF) == 0 && !force_slow;
-    const bool force_giant = !force_slow && getenv("BVG_GIANT") && atoi(getenv("BVG_GIANT")) == 2;   // tests: every block through the giant kernel
-    if (!batch && rows_default && g->skip_mode == 0 && !plp->skip_state.load(std::memory_order_acquire) && !getenv("BVG_NOSKIP") &&
-        (to - from) >= sh->p.nodes / 4 && (to - from) >= 4096) { r = build_skip(g, plp); if (r) return r; }
+    const bool force_giant = !force_slow && knob("BVG_GIANT") && atoi(knob("BVG_GIANT")) == 2;   // tests: every block through the giant kernel
     const Plan& pl = *plp;
     const bool wide = sh->wide || g->tun.force_wide;
     // block range
@@ -374,6 +391,18 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         if (hi > pl.nblk) hi = pl.nblk;
         nblocks = hi > lo ? hi - lo : 0;
     }
+    // The residual skip index is built the first time it would pay: a SCAN of >= 4096 nodes indexes the blocks it covers (a shard
+    // of a multi-GPU scan builds its own part only; a later scan outside them indexes the whole graph), a materialising call
+    // the whole graph once it covers a quarter of it.  bvg_build_index() does the same explicitly.
+    if (!batch && rows_default && g->skip_mode == 0 && !knob("BVG_NOSKIP") && (to - from) >= 4096 && nblocks) {
+        std::shared_ptr<SkipIndex> cur = std::atomic_load(&plp->skip);
+        const bool covered = cur && cur->blk_lo <= lo && lo + nblocks <= cur->blk_hi;
+        if (!covered && (!materialise || (to - from) >= sh->p.nodes / 4)) {
+            r = materialise ? build_skip(g, plp, 0, pl.nblk) : build_skip(g, plp, lo, lo + nblocks);
+            if (r) return r;
+        }
+    }
+    const std::shared_ptr<SkipIndex> skx = g->skip_mode == 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));   // held for the whole call
 
     if (nblocks > g->fail_cap) {                            // every block may fail over to the slow path
         (void)hipFree(g->d_fail); g->d_fail = nullptr;
@@ -389,9 +418,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.blk_first = batch ? batch->d_first : pl.d_first; a.blk_halo = batch ? batch->d_halo : pl.d_halo; a.blk_mask = batch ? batch->d_mask : pl.d_mask;
     a.work_list = nullptr; a.blk_lo = lo; a.batch = batch ? 1u : 0u;
     a.window = sh->p.window_size; a.min_interval = sh->p.min_interval_length; a.cod = codings_of(sh->p);
-    a.node_base = g->node_base; a.acc = g->d_acc; a.acc_mask = getenv("BVG_NOSTRIPE") ? 0u : kAccStripes - 1; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
+    a.node_base = g->node_base; a.acc = g->d_acc; a.acc_mask = knob("BVG_NOSTRIPE") ? 0u : kAccStripes - 1; a.cum = d_cum; a.succ = d_succ; a.outdeg = d_outdeg;
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
-    a.dbg = getenv("BVG_DBG") ? (uint32_t)strtoul(getenv("BVG_DBG"), nullptr, 10) : 0;
+    a.dbg = knob("BVG_DBG") ? (uint32_t)strtoul(knob("BVG_DBG"), nullptr, 10) : 0;
 #ifndef BVG_PROF
     a.dbg &= (16u | 32u | 64u);                             // forcing an emission form and the work counters leave the results alone; the
                                                             // phase-skipping bits (1, 2, 4, 128) exist in the profiling build only
@@ -401,12 +430,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     {
         const double avg_d = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
         a.emit_tasks = (sh->p.window_size == 0 || avg_d >= 24.0) ? 1u : 0u;
-        if (getenv("BVG_EMIT")) a.emit_tasks = (uint32_t)strtoul(getenv("BVG_EMIT"), nullptr, 10) ? 1u : 0u;
-        a.pass_cost = getenv("BVG_PASSCOST") ? (uint32_t)strtoul(getenv("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
+        if (knob("BVG_EMIT")) a.emit_tasks = (uint32_t)strtoul(knob("BVG_EMIT"), nullptr, 10) ? 1u : 0u;
+        a.pass_cost = knob("BVG_PASSCOST") ? (uint32_t)strtoul(knob("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
-    if (!batch && rows_default && pl.skip_total && pl.skip_wide == wide && g->skip_mode != 1 && (g->skip_mode == 2 || pl.skip_state.load(std::memory_order_acquire))) {
-        a.skip_first = pl.d_skip_first; a.skip_bit = pl.d_skip_bit; a.skip_val = pl.d_skip_val; a.skip_fmt = pl.d_skip_fmt;
+    if (!batch && rows_default && skx && skx->wide == wide) {
+        a.skip_first = skx->d_first; a.skip_bit = skx->d_bit; a.skip_val = skx->d_val; a.skip_fmt = skx->d_fmt;
     }
 #ifdef BVG_EXPERIMENTAL
     const bool stream = (g->tun.reserved & 0xFF) == 2;     // A/B switch: the streaming data-flow kernel as tier 0
@@ -423,7 +452,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         while (words < 1024 && (double)words * 32.0 < bits_per_node * 64.0 * 1.5) words *= 2;
         a.lds_stage_words = words;
     }
-    if (getenv("BVG_STAGE")) a.lds_stage_words = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(getenv("BVG_STAGE"), nullptr, 10) & ~3u, 64u), 2048u);   // (the skip entries hold 16-bit offsets into a record)
+    if (knob("BVG_STAGE")) a.lds_stage_words = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(knob("BVG_STAGE"), nullptr, 10) & ~3u, 64u), 2048u);   // (the skip entries hold 16-bit offsets into a record)
 
     // Workgroup variant of the row kernel (several wavefronts share one pool): scan mode, default codings, 32-bit successors
     int wg_nw = 0;
@@ -431,8 +460,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const Codings& c = a.cod;
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
         // experimental (BVG_WG=2|4; measured: +4 % at 2 wavefronts on the eu shape, slower on sparse graphs and at 4): off by default
-        if (getenv("BVG_WG") && !materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) {
-            const int w = atoi(getenv("BVG_WG")); wg_nw = (w == 2 || w == 4) ? w : 0;
+        if (kExperimental && knob("BVG_WG") && !materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) {
+            const int w = atoi(knob("BVG_WG")); wg_nw = (w == 2 || w == 4) ? w : 0;
         }
     }
     // the big-LDS classes hold few workgroups per CU: several wavefronts per pool paid there in round 1 (BVG_WGC=2|4|8 selects them)
@@ -440,7 +469,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     {
         const Codings& c = a.cod;
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_class = getenv("BVG_WGC") ? atoi(getenv("BVG_WGC")) : 0;   // round 1 (8 GiB eu): 258.6 ms (0), 254.9 (2), 254.6 (4); end of round 2, after the single-wavefront kernel got the window overlay and the leaf pass (2 GiB eu15 / eu): 53.2 / 53.4 ms (0), 53.3 / 53.8 (2), 54.2 / 54.6 (4), 56.5 / 57.7 (8) -- the workgroup kernel is opt-in again
+        if (!materialise && !wide && !batch && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default) wg_class = kExperimental && knob("BVG_WGC") ? atoi(knob("BVG_WGC")) : 0;   // round 1 (8 GiB eu): 258.6 ms (0), 254.9 (2), 254.6 (4); end of round 2, after the single-wavefront kernel got the window overlay and the leaf pass (2 GiB eu15 / eu): 53.2 / 53.4 ms (0), 53.3 / 53.8 (2), 54.2 / 54.6 (4), 56.5 / 57.7 (8) -- the workgroup kernel is opt-in again
         if (wg_class != 2 && wg_class != 4 && wg_class != 8) wg_class = 0;
     }
     // The flow scan kernel as tier 0 (bvg_flow.hip): full scans, default codings, 32-bit successors, windows up to 64.  Its LDS holds
@@ -449,9 +478,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     {
         const Codings& c = a.cod;
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-        if (getenv("BVG_FLOW") && atoi(getenv("BVG_FLOW")) && !materialise && !wide && !batch && dflt && g->skip_mode == 0 && rows_default && sh->p.window_size <= kMaxWindow) {
+        if (kExperimental && knob("BVG_FLOW") && atoi(knob("BVG_FLOW")) && !materialise && !wide && !batch && dflt && g->skip_mode == 0 && rows_default && sh->p.window_size <= kMaxWindow) {
             flow = true;
-            flow_ring = getenv("BVG_FLOW_RING") ? (uint32_t)std::min(8192, std::max(512, atoi(getenv("BVG_FLOW_RING")))) : 1536u;
+            flow_ring = knob("BVG_FLOW_RING") ? (uint32_t)std::min(8192, std::max(512, atoi(knob("BVG_FLOW_RING")))) : 1536u;
             const size_t per = flow_scratch_bytes_per_wave(sh->p.window_size);
             const uint32_t per_cu = (uint32_t)std::min<size_t>(20, (160 * 1024) / (flow_lds_bytes(flow_ring) + 1536 + 64));
             const uint32_t waves = 256u * std::max(1u, per_cu);
@@ -473,7 +502,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     {
         const Codings& c = a.cod;
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-        giant_ok = dflt && rows_default && sh->p.window_size <= kMaxWindow && !(getenv("BVG_GIANT") && atoi(getenv("BVG_GIANT")) == 0);
+        giant_ok = dflt && rows_default && sh->p.window_size <= kMaxWindow && !(knob("BVG_GIANT") && atoi(knob("BVG_GIANT")) == 0);
     }
     uint32_t launches = 0, slow_blocks = 0;
     bool predicted_run = false;                        // cascade outcomes of a predicted run are remembered in g->pred
@@ -495,7 +524,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         HIPCHK(hipStreamSynchronize(g->stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
         kernel_ms += ms;
-        if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] %s: %zu blocks, %.3f ms\n", what, nb, ms);
+        if (dbg_on()) fprintf(stderr, "[bvg] %s: %zu blocks, %.3f ms\n", what, nb, ms);
         return 0;
     };
 
@@ -512,7 +541,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         if (stream) {                                       // list ring: power of two
             uint64_t want = (uint64_t)(avg * 72.0), cap = 2048;
             while (cap * 2 <= want && cap < (wide ? 8192u : 16384u)) cap *= 2;
-            if (getenv("BVG_POOL")) cap = strtoull(getenv("BVG_POOL"), nullptr, 10);
+            if (knob("BVG_POOL")) cap = strtoull(knob("BVG_POOL"), nullptr, 10);
             a.lds_pool_elems = (uint32_t)cap; a.lds_scr_elems = 0;
         } else {
             const bool task = a.emit_tasks != 0;                          // task emission parks the row's residuals beside the lists
@@ -521,7 +550,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (wg_nw) {
                 // workgroups per CU are bounded by registers (wavefronts per SIMD): give each the LDS share of that count
                 uint64_t wgs = wg_nw == 4 ? 5 : 8;
-                if (getenv("BVG_WG_BLOCKS")) wgs = std::max<uint64_t>(1, strtoull(getenv("BVG_WG_BLOCKS"), nullptr, 10));
+                if (knob("BVG_WG_BLOCKS")) wgs = std::max<uint64_t>(1, strtoull(knob("BVG_WG_BLOCKS"), nullptr, 10));
                 const uint64_t share = ((160 * 1024) / wgs) & ~255ull, fixed = (uint64_t)a.lds_stage_words * 4 + rows_wg_static_lds(wg_nw) + 256;
                 const uint64_t fit = share > fixed ? ((share - fixed) / esz) * 8 / 9 : 1024;      // pool + pool/8 of scratch
                 pool = std::min<uint64_t>(std::max<uint64_t>(pool, fit & ~63ull), 12288);
@@ -539,22 +568,22 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // the four SIMDs unevenly: 9 and 11 measured below 8 and 10) whose pool holds ~48 average lists; dense graphs end at
                 // 8-10, sparse ones at the 16 the registers allow (profiles/r02: eu 10 per CU 118.8 G edges/s vs 8: 117.3, 9: 113.8;
                 // eu15 8: 121.6, 9: 111.0, 10: 111.3).
-                if (!getenv("BVG_STAGE")) {
+                if (!knob("BVG_STAGE")) {
                     for (uint64_t w : {20ull, 16ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
                         uint64_t pw = wide ? 4096 : 8192;
                         while (pw > 1024 && lds_cu / foot(pw) < w) pw -= 32;
                         if (lds_cu / foot(pw) >= w && ((double)pw >= 48.0 * avg || w == 4)) { pool = pw; waves = lds_cu / foot(pw); a.lds_stage_words = std::min<uint32_t>(a.lds_stage_words, 512); break; }
                     }
                 }
-                if (getenv("BVG_WAVES")) {                                 // experiments: aim at this many resident wavefronts per CU
-                    const uint64_t w = std::max<uint64_t>(1, strtoull(getenv("BVG_WAVES"), nullptr, 10));
+                if (knob("BVG_WAVES")) {                                 // experiments: aim at this many resident wavefronts per CU
+                    const uint64_t w = std::max<uint64_t>(1, strtoull(knob("BVG_WAVES"), nullptr, 10));
                     uint64_t pw = wide ? 4096 : 8192;
                     while (pw > 1024 && lds_cu / foot(pw) < w) pw -= 64;
                     pool = pw; waves = lds_cu / foot(pw);
                 }
                 while (pool + 32 <= (wide ? 4096u : 8192u) && lds_cu / foot(pool + 32) == waves) pool += 32;
             }
-            if (getenv("BVG_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(getenv("BVG_POOL"), nullptr, 10), 256), wide ? 6144 : 12288);
+            if (knob("BVG_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(knob("BVG_POOL"), nullptr, 10), 256), wide ? 6144 : 12288);
             a.lds_pool_elems = (uint32_t)pool; a.lds_scr_elems = (uint32_t)std::max<uint64_t>(256, pool / 8);
         }
         if (batch) {                                        // one block per request: the even entries of the per-call plan
@@ -564,7 +593,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         }
         const uint32_t max_pool = wide ? 6144 : 12288;
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
-        const bool predict = !batch && !stream && !legacy && pl.h_maxd.size() == pl.nblk && !getenv("BVG_NOPREDICT");
+        const bool predict = !batch && !stream && !legacy && pl.h_maxd.size() == pl.nblk && !knob("BVG_NOPREDICT");
         if (predict) {
             // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
             bvg_graph::Pred& pd = g->pred;
@@ -611,7 +640,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (ngiant) {
                 // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
                 gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, getenv("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(getenv("BVG_GBATCH"))) : 1024u);
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : 1024u);
                 const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
                 if (bytes > g->giant_ws_bytes) {
                     if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
@@ -624,7 +653,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
             off += pd.count[0];
             size_t offc[7]; { size_t o = 0; for (int c = 0; c < 7; c++) { offc[c] = o; o += pd.count[c]; } }
-            const bool tier0_first = getenv("BVG_ORDER") && atoi(getenv("BVG_ORDER")) == 1;
+            const bool tier0_first = knob("BVG_ORDER") && atoi(knob("BVG_ORDER")) == 1;
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
@@ -642,7 +671,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (!pd.count[c]) continue;
                 DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_rows_any(ac, pd.count[c], g->side[getenv("BVG_SIDE6") ? c : 1 + (c & 1)], true);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
+                launch_rows_any(ac, pd.count[c], g->side[knob("BVG_SIDE6") ? c : 1 + (c & 1)], true);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
                 launches++;
             }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
@@ -651,7 +680,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             HIPCHK(hipStreamSynchronize(g->stream));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
             kernel_ms += ms;
-            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant + %u generic blocks, %.3f ms\n",
+            if (dbg_on()) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant + %u generic blocks, %.3f ms\n",
                                              pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], pd.count[6], ms);
             slow_blocks = nblocks - pd.count[0];
             predicted_run = true;
@@ -685,7 +714,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const uint32_t max_pool = wide ? 6144 : 12288;
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
         std::vector<uint32_t> bins[4], rest;
-        if (getenv("BVG_DEBUG")) { size_t h[8] = {0}; for (uint32_t nd : need) h[nd >= 0xFFFFFFF0u ? (nd & 7) : 0]++; fprintf(stderr, "[bvg] failures: pool %zu, window %zu, huge %zu, blocks-scratch %zu, intervals-scratch %zu, code %zu, other %zu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[7]); }
+        if (dbg_on()) { size_t h[8] = {0}; for (uint32_t nd : need) h[nd >= 0xFFFFFFF0u ? (nd & 7) : 0]++; fprintf(stderr, "[bvg] failures: pool %zu, window %zu, huge %zu, blocks-scratch %zu, intervals-scratch %zu, code %zu, other %zu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[7]); }
         for (size_t i = 0; i < work.size(); i++) {
             int c = 3;
             if (!stream && !legacy && need[i] < 0xFFFFFFF0u) { c = 0; while (c < 3 && classes[c] < need[i]) c++; if (classes[c] < need[i]) c = -1; }
@@ -778,10 +807,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;
         res->index_bytes = (uint64_t)(to - from + 1) * (sh->offs.lo ? 4 : 8) + (sh->offs.lo ? ((uint64_t)(to - from) >> kOffShift) * 8 : 0) + (uint64_t)nblocks * 20;
-        if (a.skip_first && pl.h_skip_first.size() > (size_t)lo + nblocks) res->index_bytes += (pl.h_skip_first[lo + nblocks] - pl.h_skip_first[lo]) * (2 + esz) + (uint64_t)nblocks * 8;
+        res->index_entries = a.skip_first && skx->h_first.size() > (size_t)lo + nblocks ? skx->h_first[lo + nblocks] - skx->h_first[lo] : 0;
+        if (a.skip_first) res->index_bytes += res->index_entries * (2 + esz) + (uint64_t)nblocks * 9;
         res->graph_bytes = 0;
     }
-    if (acc[3] && getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] error bits 0x%llx\n", acc[3]);
+    if (acc[3] && dbg_on()) fprintf(stderr, "[bvg] error bits 0x%llx\n", acc[3]);
     if (acc[3] & ERR_REF_RANGE) return BVG_E_STATE;
     if (acc[3] & (ERR_OVERRUN | ERR_MALFORMED)) return BVG_E_EOF;
     return 0;
@@ -834,7 +864,7 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
     sh->device = device; sh->p = *p; sh->nbytes = nbytes;
     // 32-bit successor arithmetic holds every node id below 2^32 - 1 (0xFFFFFFFF is the lists' sentinel); the reference's own line between
     // the int and the long library is 2^31 because Java ints are signed -- nothing here is
-    sh->wide = p->nodes > (int64_t)0xFFFFFF00ll || (getenv("BVG_WIDE_FROM_2_31") != nullptr && p->nodes > (int64_t)0x7FFFFFFF);
+    sh->wide = p->nodes > (int64_t)0xFFFFFF00ll || (knob("BVG_WIDE_FROM_2_31") != nullptr && p->nodes > (int64_t)0x7FFFFFFF);
     const int64_t n = p->nodes;
     if (d_graph_in) { sh->d_graph = (uint8_t*)d_graph_in; sh->own_graph = false; sh->padded = ((nbytes + 15) & ~15ull) + 16; }
     else {
@@ -847,7 +877,7 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
     }
     // The index is kept packed (bvg_kernels.h: Offsets).  A caller's device array is packed into memory of our own and not referenced
     // afterwards; BVG_WIDE_OFFSETS=1 or a distance that does not fit 32 bits keeps the plain 64-bit form.
-    const bool keep_wide = getenv("BVG_WIDE_OFFSETS") != nullptr;
+    const bool keep_wide = knob("BVG_WIDE_OFFSETS") != nullptr;
     if (packed) { sh->d_off_lo = packed->lo; sh->d_off_hi = packed->hi; sh->offs = Offsets{packed->lo, packed->hi, nullptr}; }
     else if (d_offsets_in) {
         int pk = keep_wide ? 1 : pack_offsets(sh, (const uint64_t*)d_offsets_in, nullptr);
@@ -876,19 +906,19 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
             // 0.7-17x the speed of the one-wavefront walk depending on the graph (profiles/r02/derive_bench.py).  Default and fall-back
             // (windows > 64, records > 64 Mbit, any error, so that the error bits are those of the plain walk): the sequential walk.
             int rounds = 0;
-            int pr = !getenv("BVG_DERIVE_PAR") ? -1 : derive_offsets_parallel(sh->d_graph, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr, &rounds);
+            int pr = !(kExperimental && knob("BVG_DERIVE_PAR")) ? -1 : derive_offsets_parallel(sh->d_graph, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr, &rounds);
             if (pr == 0) {
                 unsigned e0 = 0;
                 if (hipMemcpy(&e0, d_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_err); release_shared(sh); return BVG_E_HIP; }
                 if (e0) { pr = -4; (void)hipMemset(d_err, 0, sizeof(unsigned)); }
             }
-            if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] derive offsets: parallel walk %s (%d rounds)\n", pr == 0 ? "ok" : "not used / failed", rounds);
+            if (dbg_on()) fprintf(stderr, "[bvg] derive offsets: parallel walk %s (%d rounds)\n", pr == 0 ? "ok" : "not used / failed", rounds);
             if (pr != 0) launch_derive_offsets(sh->d_graph, sh->padded, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr);
             unsigned herr = 0;
             hipError_t e = hipMemcpy(&herr, d_err, sizeof(unsigned), hipMemcpyDeviceToHost);
             (void)hipFree(d_err);
             if (e != hipSuccess) { release_shared(sh); return BVG_E_HIP; }
-            if (getenv("BVG_DEBUG")) { uint64_t last = 0; (void)hipMemcpy(&last, d_wide + n, 8, hipMemcpyDeviceToHost); fprintf(stderr, "[bvg] derive offsets: err=%u end=%llu of %llu bits\n", herr, (unsigned long long)last, (unsigned long long)nbytes * 8); }
+            if (dbg_on()) { uint64_t last = 0; (void)hipMemcpy(&last, d_wide + n, 8, hipMemcpyDeviceToHost); fprintf(stderr, "[bvg] derive offsets: err=%u end=%llu of %llu bits\n", herr, (unsigned long long)last, (unsigned long long)nbytes * 8); }
             if (herr) { release_shared(sh); return (herr & ERR_REF_RANGE) ? BVG_E_STATE : BVG_E_EOF; }
         }
         int pk = keep_wide ? 1 : pack_offsets(sh, d_wide, nullptr);
@@ -1271,7 +1301,7 @@ static int transpose_impl(bvg_graph* g, uint64_t* toffsets, int64_t* tsucc, uint
     if (g->node_base != 0) return BVG_E_ARG;                 // a shard's targets leave its node range: transpose the whole graph
     const int64_t n = sh->p.nodes;
     HIPCHK(hipSetDevice(sh->device));
-    const bool dbgt = getenv("BVG_DEBUG") != nullptr;
+    const bool dbgt = dbg_on();
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto tA = now();
@@ -1438,7 +1468,7 @@ static int bvg_split_by_bits_impl(bvg_graph* g, int k, int64_t* bounds) {
 // Shard bounds of a k-way split of the node range (ImmutableGraph.splitNodeIterators, IG:405-436): BVG_BALANCE_NODES is the
 // reference's own rule (ceil(n/k) nodes each, IG:415-433), BVG_BALANCE_BITS / _ARCS the balanced variants above.  Cached per
 // (k, balance) in the shared part of the handle, so every flyweight and every later call agrees on them.
-int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds) {
+static int bvg_shard_bounds_impl(bvg_graph* g, int k, int balance, int64_t* bounds) {
     if (!g || !bounds || k < 1 || balance < BVG_BALANCE_NODES || balance > BVG_BALANCE_ARCS) return BVG_E_ARG;
     Shared* sh = g->sh;
     const uint64_t key = ((uint64_t)k << 2) | (uint64_t)balance;
@@ -1459,42 +1489,70 @@ int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds) {
 }
 
 // Shard r of k: the scan of nodes [bounds[r], bounds[r+1]) (one rank of the multi-GPU scan; the caller reduces {arcs, chk}).
-int bvg_scan_shard(bvg_graph* g, int k, int r, int balance, bvg_scan_result* out, int64_t* from, int64_t* to) {
+static int bvg_scan_shard_impl(bvg_graph* g, int k, int r, int balance, bvg_scan_result* out, int64_t* from, int64_t* to) {
     if (!g || !out || k < 1 || r < 0 || r >= k) return BVG_E_ARG;
     std::vector<int64_t> b((size_t)k + 1);
-    int rc = bvg_shard_bounds(g, k, balance, b.data()); if (rc) return rc;
+    int rc = bvg_shard_bounds_impl(g, k, balance, b.data()); if (rc) return rc;
     if (from) *from = b[(size_t)r];
     if (to) *to = b[(size_t)r + 1];
-    return bvg_scan(g, b[(size_t)r], b[(size_t)r + 1], out);
+    return bvg_scan_impl(g, b[(size_t)r], b[(size_t)r + 1], out);
 }
 
 // One process, several GPUs (what a JVM host has): handle i scans shard i of ngpu on its own device, all at once (one host
 // thread each), and the per-shard {nodes, arcs, chk} are summed on the host -- 24 bytes, so no device collective is involved
 // (the one-process-per-GPU form of the same reduction is bench.py's RCCL all-reduce).  The handles must describe the same graph
-// (replicas opened on different devices, or bvg_copy() flyweights on one device).  kernel_ms = the slowest shard.
-int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_result* total, bvg_scan_result* per_shard) {
+// (replicas opened on different devices, or bvg_copy() flyweights on one device) and be DISTINCT: a handle owns one stream and
+// one set of result words.  kernel_ms = the slowest shard.
+static int bvg_scan_multi_impl(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_result* total, bvg_scan_result* per_shard) {
     if (!per_gpu || ngpu < 1 || !total) return BVG_E_ARG;
     for (int i = 0; i < ngpu; i++) {
         if (!per_gpu[i]) return BVG_E_ARG;
+        for (int j = 0; j < i; j++) if (per_gpu[j] == per_gpu[i]) return BVG_E_ARG;              // two threads on one handle would share its stream and results
         const bvg_params &a = per_gpu[0]->sh->p, &b = per_gpu[i]->sh->p;
         if (a.nodes != b.nodes || a.arcs != b.arcs || per_gpu[0]->sh->total_bits != per_gpu[i]->sh->total_bits) return BVG_E_ARG;
     }
     std::vector<int64_t> bounds((size_t)ngpu + 1);
-    int rc = bvg_shard_bounds(per_gpu[0], ngpu, balance, bounds.data()); if (rc) return rc;
+    int rc = bvg_shard_bounds_impl(per_gpu[0], ngpu, balance, bounds.data()); if (rc) return rc;
     std::vector<bvg_scan_result> res((size_t)ngpu);
-    std::vector<int> st((size_t)ngpu, 0);
+    std::vector<int> st((size_t)ngpu, BVG_E_HIP);
     std::vector<std::thread> th;
+    th.reserve((size_t)ngpu);
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};   // also when emplace_back throws
     for (int i = 0; i < ngpu; i++)
-        th.emplace_back([&, i] { st[(size_t)i] = bvg_scan(per_gpu[i], bounds[(size_t)i], bounds[(size_t)i + 1], &res[(size_t)i]); });
+        th.emplace_back([&, i] { st[(size_t)i] = guarded([&] { return bvg_scan_impl(per_gpu[i], bounds[(size_t)i], bounds[(size_t)i + 1], &res[(size_t)i]); }); });
     for (auto& t : th) t.join();
     memset(total, 0, sizeof *total);
     for (int i = 0; i < ngpu; i++) {
         if (st[(size_t)i]) return st[(size_t)i];
         const bvg_scan_result& x = res[(size_t)i];
         total->nodes += x.nodes; total->arcs += x.arcs; total->chk += x.chk; total->graph_bytes += x.graph_bytes; total->index_bytes += x.index_bytes;
-        total->launches += x.launches; total->slow_blocks += x.slow_blocks;
+        total->launches += x.launches; total->slow_blocks += x.slow_blocks; total->index_entries += x.index_entries;
         if (x.kernel_ms > total->kernel_ms) total->kernel_ms = x.kernel_ms;
         if (per_shard) per_shard[i] = x;
+    }
+    return 0;
+}
+
+// the skip index (and the validation that comes with it) for the blocks of [from, to), built now
+static int bvg_build_index_impl(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, uint64_t* bytes) {
+    if (!g) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    if (from < 0 || to > sh->p.nodes || from > to) return BVG_E_ARG;
+    HIPCHK(hipSetDevice(sh->device));
+    if (entries) *entries = 0;
+    if (bytes) *bytes = 0;
+    const bool rows_ok = (g->tun.reserved & 0xFF) == 0 && !g->tun.force_slow && sh->p.window_size <= kMaxWindow;
+    if (!rows_ok || from == to) return 0;                                   // the global-memory kernels use no index
+    std::shared_ptr<Plan> plp;
+    int r = build_plan(g, block_bits_of(g), plp); if (r) return r;
+    const std::vector<uint64_t>& hf = plp->h_first;
+    uint32_t lo = (uint32_t)(std::upper_bound(hf.begin(), hf.end(), (uint64_t)from) - hf.begin()); lo = lo ? lo - 1 : 0;
+    uint32_t hi = (uint32_t)(std::lower_bound(hf.begin(), hf.end(), (uint64_t)to) - hf.begin()); if (hi > plp->nblk) hi = plp->nblk;
+    if (hi > lo) { r = build_skip(g, plp, lo, hi); if (r) return r; }
+    std::shared_ptr<SkipIndex> ix = std::atomic_load(&plp->skip);
+    if (ix) {
+        if (entries) *entries = ix->total;
+        if (bytes) *bytes = ix->total * (ix->wide ? 10u : 6u) + (uint64_t)plp->nblk * 9u;
     }
     return 0;
 }
@@ -1528,6 +1586,13 @@ static int bvg_tile_impl(const bvg_graph* base, int64_t copies, bvg_graph** out)
 }
 
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) { return guarded([&] { return bvg_scan_impl(g, from, to, out); }); }
+// Shard bounds of a k-way split of the node range (ImmutableGraph.splitNodeIterators, IG:405-436): BVG_BALANCE_NODES is the
+// reference's own rule (ceil(n/k) nodes each, IG:415-433), BVG_BALANCE_BITS / _ARCS the balanced variants.  Cached per
+// (k, balance) in the shared part of the handle, so every flyweight and every later call agrees on them.
+int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds) { return guarded([&] { return bvg_shard_bounds_impl(g, k, balance, bounds); }); }
+int bvg_scan_shard(bvg_graph* g, int k, int r, int balance, bvg_scan_result* out, int64_t* from, int64_t* to) { return guarded([&] { return bvg_scan_shard_impl(g, k, r, balance, out, from, to); }); }
+int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_result* total, bvg_scan_result* per_shard) { return guarded([&] { return bvg_scan_multi_impl(per_gpu, ngpu, balance, total, per_shard); }); }
+int bvg_build_index(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, uint64_t* bytes) { return guarded([&] { return bvg_build_index_impl(g, from, to, entries, bytes); }); }
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) { return guarded([&] { return bvg_successors_batch_impl(g, nodes, count, outdeg, succ, succ_cap, n_succ); }); }
 int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) { return guarded([&] { return bvg_tile_impl(base, copies, out); }); }
 int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_arcs_impl(g, k, bounds); }); }

@@ -173,7 +173,7 @@ int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, in
         else hipLaunchKernelGGL((derive_round_kernel<false>), grid, block, 0, s, graph, nbytes, nbits, chunk_bits, nchunks, window, min_interval, cod, st, win, changed, (const uint64_t*)nullptr, n, (uint64_t*)nullptr, d_err);
         uint32_t ch = 0;
         if (hipMemcpyAsync(&ch, changed, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return done(-2);
-        if (getenv("BVG_DEBUG") && (rounds < 12 || rounds % 32 == 0)) fprintf(stderr, "[bvg] derive round %d: %u of %u chunks changed\n", rounds, ch, nchunks);
+        if (dbg_on() && (rounds < 12 || rounds % 32 == 0)) fprintf(stderr, "[bvg] derive round %d: %u of %u chunks changed\n", rounds, ch, nchunks);
         if (!ch) break;
     }
     if (rounds_out) *rounds_out = rounds + 1;

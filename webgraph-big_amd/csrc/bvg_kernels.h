@@ -3,9 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 #include "bvg_device.h"
 
 namespace bvg {
+
+// Environment switches force tiers / emission forms for the parity tests and the experiments under profiles/.  A product process
+// never looks at them: they are live only when BVG_TEST_KNOBS is set when the library is first used (tests/conftest.py and the
+// profiling scripts set it).  BVG_DEBUG (per-tier timing lines on stderr) is honoured always, read once.
+inline const char* knob(const char* name) { static const bool live = getenv("BVG_TEST_KNOBS") != nullptr; return live ? getenv(name) : nullptr; }
+inline bool dbg_on() { static const bool on = getenv("BVG_DEBUG") != nullptr; return on || knob("BVG_DEBUG") != nullptr; }
 
 // LDS geometry of the fast (one wavefront per node block) decode kernel.
 #ifndef BVG_SKIP_MIN
@@ -89,18 +97,28 @@ struct DecodeArgs {
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
 // the lean LDS-resident row kernel (bvg_rows.hip): tiers 0 and 1
 void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
-// the same with one workgroup of nw (2 or 4) wavefronts per block sharing the pool (bvg_rows_wg.hip): scan mode, default
-// codings, 32-bit successors only
+// Experiments that lost to the row kernel are compiled only by `make experimental` (-DBVG_EXPERIMENTAL): the row kernel
+// with one workgroup of nw wavefronts per block sharing the pool (bvg_rows_wg.hip), the streaming data-flow kernel
+// (bvg_stream.hip), the flow scan kernel (bvg_flow.hip), the chunk-parallel offsets derivation (bvg_derive.hip).
+#ifdef BVG_EXPERIMENTAL
+constexpr bool kExperimental = true;
 void launch_rows_wg_decode(const DecodeArgs& a, uint32_t nblocks, int nw, hipStream_t s);
 size_t rows_wg_static_lds(int nw);
-// the streaming data-flow kernel (bvg_stream.hip): fast path; lds_pool_elems must be a power of two
 void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
-
-// the flow scan kernel (bvg_flow.hip): tier 0 of full scans with default codings and 32-bit successors.  Persistent: `waves`
-// wavefronts take the nblocks blocks in turn, each with flow_scratch_bytes_per_wave(window) bytes of `scratch`.
 size_t flow_scratch_bytes_per_wave(int window);
 size_t flow_lds_bytes(uint32_t ring_cap);
 void launch_flow_scan(const DecodeArgs& a, uint32_t nblocks, uint32_t waves, void* scratch, uint32_t ring_cap, hipStream_t s);
+int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod, uint64_t* offsets, unsigned* err,
+                            hipStream_t s, int* rounds);
+#else
+constexpr bool kExperimental = false;
+inline void launch_rows_wg_decode(const DecodeArgs&, uint32_t, int, hipStream_t) {}
+inline size_t rows_wg_static_lds(int) { return 0; }
+inline size_t flow_scratch_bytes_per_wave(int) { return 0; }
+inline size_t flow_lds_bytes(uint32_t) { return 0; }
+inline void launch_flow_scan(const DecodeArgs&, uint32_t, uint32_t, void*, uint32_t, hipStream_t) {}
+inline int derive_offsets_parallel(const uint8_t*, uint64_t, int64_t, int, int, Codings, uint64_t*, unsigned*, hipStream_t, int*) { return -1; }
+#endif
 
 // tier 2a (bvg_giant.hip): blocks with lists / records too large for LDS, one 256-thread workgroup per block, work areas as for the
 // generic kernel (a.gpool / a.gscr); default codings and windows <= kMaxWindow only
@@ -132,11 +150,6 @@ void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets
 // one wavefront parses the stream sequentially (all lanes in step, LDS-staged); offsets[n+1] out, err[0] != 0 on a bad stream
 void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod,
                            uint64_t* offsets, unsigned* err, hipStream_t s);
-
-// the same in parallel (bvg_derive.hip): chunks of the stream walked speculatively and iterated to the one consistent walk; 0 = done
-// (err[0] != 0 on a bad stream), < 0 = not applicable / did not settle: fall back to launch_derive_offsets
-int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod, uint64_t* offsets, unsigned* err,
-                            hipStream_t s, int* rounds);
 
 // BVGraph.store on the device (bvg_encode.hip): adjacency in CSR form (device pointers) -> .graph bytes + offsets (hipMalloc'ed here)
 int encode_store_dev(const bvg_params& p, const uint64_t* d_adj_off, const int64_t* d_adj, int64_t n, int64_t chunk_nodes, hipStream_t s,

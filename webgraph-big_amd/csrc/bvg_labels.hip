@@ -40,7 +40,7 @@ struct bvg_labels {
 namespace bvg {
 namespace {
 
-#define LCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { if (getenv("BVG_DEBUG")) fprintf(stderr, "[bvg] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+#define LCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { if (dbg_on()) fprintf(stderr, "[bvg] %s -> %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
                         return _e == hipErrorOutOfMemory ? BVG_E_NOMEM : BVG_E_HIP; } } while (0)
 
 __global__ void __launch_bounds__(256) labels_kernel(const uint8_t* stream, uint64_t limit_byte, const uint64_t* loff, int64_t from, int64_t count,

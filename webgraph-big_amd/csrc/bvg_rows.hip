@@ -891,7 +891,7 @@ void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
                        a.cod.block == BVG_GAMMA && a.cod.residual == BVG_ZETA);
     const bool task0 = a.emit_tasks != 0;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * (wide ? 8 : 4) + (task0 ? 0 : (size_t)a.lds_stage_words * 4);   // (task variant: the window lies inside the pool)
-    if (getenv("BVG_LDSPAD")) dyn += (size_t)atoi(getenv("BVG_LDSPAD"));   // occupancy experiments: unused LDS behind the window
+    if (knob("BVG_LDSPAD")) dyn += (size_t)atoi(knob("BVG_LDSPAD"));   // occupancy experiments: unused LDS behind the window
     const bool task = a.emit_tasks != 0;
 #define BVG_RL(T, M) do { if (task) { if (gen) hipLaunchKernelGGL((rows_kernel<T, M, true, true>), grid, block, dyn, s, a); \
                                       else hipLaunchKernelGGL((rows_kernel<T, M, false, true>), grid, block, dyn, s, a); } \
