@@ -71,6 +71,8 @@ typedef struct bvg_scan_result {
     uint32_t launches;     /* kernel launches issued (1 + slow-path relaunches) */
     uint32_t slow_blocks;  /* node blocks that had to take the global-memory slow path */
     uint64_t index_entries; /* residual skip entries of the scanned blocks that an index was present for (0 = the scan ran index-less) */
+    uint32_t lean_blocks;  /* node blocks launched on the lean scan kernel (validated blocks of an indexed scan; bvg_scan.hip) */
+    uint32_t reserved0;
 } bvg_scan_result;
 
 typedef struct bvg_graph bvg_graph;

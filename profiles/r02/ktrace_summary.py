@@ -3,7 +3,7 @@
 usage: ktrace_summary.py <kernel_trace.csv>"""
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
-dec = [r for r in rows if any(k in r['Kernel_Name'] for k in ('rows_kernel', 'rows_wg_kernel', 'decode_kernel', 'reduce_acc', 'flat_kernel'))]
+dec = [r for r in rows if any(k in r['Kernel_Name'] for k in ('rows_kernel', 'scan_kernel', 'giant_kernel', 'rows_wg_kernel', 'decode_kernel', 'reduce_acc', 'flat_kernel'))]
 dec.sort(key=lambda r: int(r['Start_Timestamp']))
 gmax = max(int(r['Grid_Size_X']) for r in dec)
 t0 = [i for i, r in enumerate(dec) if int(r['Grid_Size_X']) >= 0.9 * gmax]

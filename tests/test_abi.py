@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(W):
 
 
 def test_struct_layouts_match_header(W):
-    assert C.sizeof(W.Params) == 56 and C.sizeof(W.ScanResult) == 64 and C.sizeof(W.Tuning) == 16
+    assert C.sizeof(W.Params) == 56 and C.sizeof(W.ScanResult) == 72 and C.sizeof(W.Tuning) == 16
 
 
 def test_host_side_entry_points(W, oracle):

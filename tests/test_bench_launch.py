@@ -17,7 +17,8 @@ def _env():
 def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--echo-ranks"], capture_output=True, text=True, timeout=300, env=_env())
     assert r.returncode == 0, r.stderr[-2000:]
-    assert sorted(l for l in r.stdout.splitlines() if l.startswith("rank ")) == ["rank %d of 3" % i for i in range(3)]
+    import re
+    assert sorted(re.findall(r"rank \d of 3", r.stdout)) == ["rank %d of 3" % i for i in range(3)]
 
 
 def test_one_rank_needs_no_launcher():

@@ -370,25 +370,6 @@ def test_symmetrize_matches_cpu_union(W, tools, oracle, small):
     assert np.array_equal(so, csoff)                                           # the offsets come with the size query
 
 
-def test_offsets_are_derived_by_the_chunk_parallel_walk(W, tools, monkeypatch):
-    """BVGraph -O (writeOffsets, BVGraph.java:2595-2609) by the opt-in chunk-parallel walk of csrc/bvg_derive.hip (speculative
-    walks iterated to the one consistent walk): it must reproduce the encoder's offsets exactly, whatever the number of rounds."""
-    monkeypatch.setenv("BVG_DERIVE_PAR", "1")
-    st = tools.synth_store(1 << 18, seed=3, synth=tools.eu_like(), threads=8)
-    big = tools.tile_host(st, 6)
-    g = W.BVGraph.from_memory(big.params, big.graph, None)
-    assert np.array_equal(g.offsets(), big.offsets)
-    r = g.scan()
-    assert r["arcs"] == big.stats["arcs"]
-    g.close()
-    # reference-free and wide-code variants, small: every coding goes through the same walk
-    for kw in (dict(window_size=0, max_ref_count=0, min_interval_length=0), dict(residual_coding=1, outdegree_coding=1, reference_coding=2, block_count_coding=5, block_coding=1)):
-        s2 = tools.synth_store(300000, seed=5, params=W.default_params(**kw), threads=4)
-        h = W.BVGraph.from_memory(s2.params, s2.graph, None)
-        assert np.array_equal(h.offsets(), s2.offsets), kw
-        h.close()
-
-
 def test_random_access_down_a_long_reference_chain(W, tools, oracle):
     """maxrefcount x window > 64: the chain of successors(x) reaches further back than a request block's halo holds (BVG:1084 recurses as
     deep as it goes).  Such requests leave the batch and are decoded through the block plan; found by tests/test_gpu_fuzz.py."""

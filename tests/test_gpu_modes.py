@@ -2,30 +2,34 @@
 
 The default policy picks the row-kernel variant per graph and the emission form per row, so the ordinary parity tests do not
 reach every combination on their small graphs; here the debug switches (BVG_EMIT, BVG_DBG 16/32, BVG_NOSKIP — read at
-every call) pin each one: level-synchronous tasks on every row, the pipelined loop inside the task variant, the pipelined
-variant alone, all of them with and without the skip index, and the experimental workgroup variant of the row kernel (BVG_WG:
-several wavefronts share one list pool) in scan mode."""
+every call, live because tests/conftest.py sets BVG_TEST_KNOBS) pin each one: level-synchronous tasks on every row, the pipelined
+loop inside the task variant, the pipelined variant alone, all of them with and without the skip index, and the lean scan kernel
+(csrc/bvg_scan.hip) that takes the validated blocks of an indexed scan."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 MODES = {
-    "tasks_every_row": dict(BVG_EMIT="1", BVG_DBG="16"),
-    "per_row_choice": dict(BVG_EMIT="1"),
-    "pipelined_rows_in_task_variant": dict(BVG_EMIT="1", BVG_DBG="32"),
+    # the row kernel's own scan paths (BVG_SCANK=0 keeps the lean scan kernel away from the validated blocks)
+    "tasks_every_row": dict(BVG_EMIT="1", BVG_DBG="16", BVG_SCANK="0"),
+    "per_row_choice": dict(BVG_EMIT="1", BVG_SCANK="0"),
+    "pipelined_rows_in_task_variant": dict(BVG_EMIT="1", BVG_DBG="32", BVG_SCANK="0"),
     "pipelined_variant": dict(BVG_EMIT="0"),
     "tasks_no_skip_index": dict(BVG_EMIT="1", BVG_DBG="16", BVG_NOSKIP="1"),
     "pipelined_no_skip_index": dict(BVG_EMIT="0", BVG_NOSKIP="1"),
-    "workgroup_2_wavefronts": dict(BVG_EMIT="1", BVG_WG="2"),
-    "workgroup_4_wavefronts": dict(BVG_EMIT="1", BVG_WG="4"),
-    "workgroup_2_no_skip_index": dict(BVG_EMIT="1", BVG_WG="2", BVG_NOSKIP="1"),
+    # the lean scan kernel (csrc/bvg_scan.hip) on every validated block: its default pool, a pool so small that rows are cut all the
+    # time and blocks fail over, and the validating pass forced onto the pipelined rows (which validate nothing: no block is lean)
+    "scan_kernel": dict(BVG_EMIT="1"),
+    "scan_kernel_small_pool": dict(BVG_EMIT="1", BVG_SCAN_POOL="704"),
+    "scan_kernel_after_pipelined_validation": dict(BVG_EMIT="1", BVG_DBG="32"),
 }
+KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL")
 
 
 @pytest.fixture(params=sorted(MODES))
 def mode(request, monkeypatch):
-    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_WG"):
+    for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[request.param].items():
         monkeypatch.setenv(k, v)
@@ -48,6 +52,9 @@ def _check(W, O, st, ranges=()):
     for a, b in ranges:
         ra, oa = g.scan(a, b), og.scan(a, b)
         assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (a, b)
+    r2 = g.scan()                                                     # steady state: index present, tiers learned
+    assert (r2["nodes"], r2["arcs"], r2["chk"]) == (o["nodes"], o["arcs"], o["chk"])
+    r["lean_blocks_steady"] = r2["lean_blocks"]
     g.close()
     return r
 
@@ -58,6 +65,10 @@ def test_dense_copy_heavy_graph(W, tools, oracle, mode):
     r = _check(W, oracle, st, ranges=[(0, 1), (5000, 20000), (4097, 4099), (19999, 20000), (6000, 6000)])
     if "no_skip" not in mode:
         assert r["index_bytes"] > 8 * 20001 + 20 * 400, "the skip index should have been built and counted"
+    if mode in ("scan_kernel", "scan_kernel_small_pool"):
+        assert r["lean_blocks_steady"] > 50, "the lean scan kernel should have taken the validated blocks"
+    else:
+        assert r["lean_blocks_steady"] == 0, mode
 
 
 def test_sparse_graph_with_reference_chains(W, tools, oracle, mode):
@@ -123,7 +134,7 @@ def test_long_records(W, tools, oracle, monkeypatch):
     """Records of 32-160 Kbit (thousands of far residuals) exceed the 4 KiB LDS stream window: the plan files their blocks under the
     global-memory kernel; lists copying every other element of such a list overflow the copy-block scratch of the LDS classes and
     cascade there too.  Whichever tier ends up decoding them, the result must agree with the oracle."""
-    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_WG"):
+    for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
     rng = np.random.default_rng(5)
     n = 1 << 23                                                              # a wide id space makes the gaps (and the codes) long

@@ -121,7 +121,7 @@ def test_every_shard_of_an_8_way_split_scans_with_its_part_of_the_skip_index(W, 
             assert g.scan(int(bounds[r]), int(bounds[r + 1]))["chk"] == c
         g.close()
     assert (arcs, chk) == (whole["arcs"], whole["chk"])
-    assert abs(ent - e_all) <= 64 * k                                   # blocks at a seam are indexed by both neighbours
+    assert 0 <= ent - e_all <= 512 * k                                  # a block at a seam is indexed by both neighbours
     ref.close()
 
 

@@ -89,7 +89,6 @@ MODES = {
     "tasks_every_row": dict(BVG_EMIT="1", BVG_DBG="16"),
     "pipelined_rows_in_task_variant": dict(BVG_EMIT="1", BVG_DBG="32"),
     "pipelined_variant": dict(BVG_EMIT="0"),
-    "workgroup_2_wavefronts": dict(BVG_EMIT="1", BVG_WG="2", BVG_DBG="16"),
     "giant_kernel_every_block": dict(BVG_GIANT="2"),          # (csrc/bvg_giant.hip: it must refuse these records, the generic kernel takes them)
 }
 
@@ -98,7 +97,7 @@ MODES = {
 @pytest.mark.parametrize("mode", sorted(MODES))
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_hip_matches_oracle_on_streams_the_encoder_never_writes(W, oracle, monkeypatch, case, mode):
-    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_WG", "BVG_GIANT"):
+    for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_GIANT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)

@@ -24,7 +24,7 @@ class ScanResult(C.Structure):
     """bvg_scan_result."""
     _fields_ = [("nodes", C.c_uint64), ("arcs", C.c_uint64), ("chk", C.c_uint64), ("graph_bytes", C.c_uint64),
                 ("index_bytes", C.c_uint64), ("kernel_ms", C.c_double), ("launches", C.c_uint32), ("slow_blocks", C.c_uint32),
-                ("index_entries", C.c_uint64)]
+                ("index_entries", C.c_uint64), ("lean_blocks", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

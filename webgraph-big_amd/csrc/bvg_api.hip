@@ -58,6 +58,7 @@ struct SkipIndex {
     uint64_t total = 0; uint64_t* d_first = nullptr; uint16_t* d_bit = nullptr; void* d_val = nullptr; uint8_t* d_fmt = nullptr;
     bool wide = false;                        // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
     std::vector<uint64_t> h_first;            // nblk + 1 entry indices (host copy: index_bytes of a range)
+    std::vector<uint8_t> h_fmt;               // host copy of d_fmt: 1 = validated by the row kernel (the lean scan kernel may take the block)
     SkipIndex() = default; SkipIndex(const SkipIndex&) = delete; SkipIndex& operator=(const SkipIndex&) = delete;
     ~SkipIndex() {
         (void)hipSetDevice(device);
@@ -136,8 +137,8 @@ struct bvg_graph {
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     std::shared_ptr<SkipIndex> skip_building;          // transient: the index the fill pass (skip_mode 2) writes
     struct Pred {
-        uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
-        std::vector<uint8_t> learned; uint64_t learned_version = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
+        uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
+        std::vector<uint8_t> learned; std::vector<uint8_t> leanfail; uint64_t learned_version = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
     } pred;
 };
 
@@ -363,6 +364,8 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_building.reset();
     if (r) return give_up();
+    ix->h_fmt.resize(nblk);
+    if (hipMemcpy(ix->h_fmt.data(), ix->d_fmt, nblk, hipMemcpyDeviceToHost) != hipSuccess) return give_up();
     ix->h_first.swap(first);
     if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0);
     return publish();
@@ -504,7 +507,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
         giant_ok = dflt && rows_default && sh->p.window_size <= kMaxWindow && !(knob("BVG_GIANT") && atoi(knob("BVG_GIANT")) == 0);
     }
-    uint32_t launches = 0, slow_blocks = 0;
+    uint32_t launches = 0, slow_blocks = 0, lean_blocks = 0;
     bool predicted_run = false;                        // cascade outcomes of a predicted run are remembered in g->pred
     double kernel_ms = 0;
     std::vector<uint32_t> work;
@@ -594,40 +597,72 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         const uint32_t max_pool = wide ? 6144 : 12288;
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
         const bool predict = !batch && !stream && !legacy && pl.h_maxd.size() == pl.nblk && !knob("BVG_NOPREDICT");
+        // The lean scan kernel (bvg_scan.hip) takes the blocks that the index-building pass has validated: scans with 32-bit
+        // successors and the default codings, index present.  BVG_SCANK=0 keeps every block on the row kernel (tests, A/B runs).
+        bool fast_ok = false;
+        DecodeArgs af = a;
+        {
+            const Codings& c = a.cod;
+            const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
+            fast_ok = predict && !materialise && !wide && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default && a.skip_first && a.skip_fmt && skx &&
+                      skx->h_fmt.size() == pl.nblk && !wg_nw && !flow && !(knob("BVG_SCANK") && atoi(knob("BVG_SCANK")) == 0);
+            if (fast_ok) {
+                // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
+                // queue) + static arrays.  Resident wavefronts per CU step down with it; take the largest even count whose pool
+                // still holds a row's worth of lists (leaves take no pool: about half the row kernel's need).
+                const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64;
+                auto scr_of = [&](uint64_t pe) { return std::max<uint64_t>(320, pe / 5); };
+                auto foot = [&](uint64_t pe) { return ((pe + scr_of(pe)) * 4 + fixed + 127) & ~127ull; };
+                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 26.0;
+                uint64_t pool = 1024, waves = 4;
+                for (uint64_t w : {20ull, 16ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
+                    if (knob("BVG_SCAN_WAVES") && w != strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) && w != 4) continue;
+                    uint64_t pw = 8192;
+                    while (pw > 768 && lds_cu / foot(pw) < w) pw -= 32;
+                    if (lds_cu / foot(pw) >= w && ((double)pw >= lists * avg + a.lds_stage_words || w == 4 || knob("BVG_SCAN_WAVES"))) { pool = pw; waves = lds_cu / foot(pw); break; }
+                }
+                while (pool + 32 <= 8192 && lds_cu / foot(pool + 32) == waves) pool += 32;
+                if (knob("BVG_SCAN_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(knob("BVG_SCAN_POOL"), nullptr, 10), 512), 12288);
+                af.lds_pool_elems = (uint32_t)pool; af.lds_scr_elems = (uint32_t)scr_of(pool);
+                af.lds_stage_words = std::min<uint32_t>(a.lds_stage_words, 512);
+                if (dbg_on()) fprintf(stderr, "[bvg] scan kernel: pool %u + scratch %u elements, window %u dwords, %llu wavefronts per CU\n", af.lds_pool_elems, af.lds_scr_elems, af.lds_stage_words, (unsigned long long)waves);
+            }
+        }
         if (predict) {
             // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
             bvg_graph::Pred& pd = g->pred;
             const uint32_t pool0 = a.lds_pool_elems;
-            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u);
+            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u) | (fast_ok ? 32u : 0u) | (fast_ok ? (af.lds_pool_elems << 8) : 0u);
             const uint64_t cap0 = flow ? 6144 : pool0;                          // the flow kernel keeps long lists in its scratch area
             const bool rekey = pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
             // what the cascade taught about a block is kept per block of the PLAN, so a scan of another node range (a shard, an
             // iterator batch, the bench's verification of single tiles) does not throw it away
             if (pd.learned.size() != pl.nblk || pd.learned_version != pl.version || pd.learned_pool0 != pool0 || pd.learned_mode != pmode) {
-                pd.learned.assign(pl.nblk, 0); pd.learned_version = pl.version; pd.learned_pool0 = pool0; pd.learned_mode = pmode;
+                pd.learned.assign(pl.nblk, 0); pd.leanfail.assign(pl.nblk, 0); pd.learned_version = pl.version; pd.learned_pool0 = pool0; pd.learned_mode = pmode;
             }
             if (rekey) pd.dirty = false;
             if (rekey || pd.dirty) {
-                std::vector<uint32_t> L[7];                                      // tier 0, four LDS classes, giants (5), the generic kernel (6)
+                std::vector<uint32_t> L[12];                                     // tier 0, four LDS classes, giants (5), the generic kernel (6); 7..11: tier 0 and the classes of the lean scan kernel
                 uint64_t gneed = 0;
                 for (uint32_t i = 0; i < nblocks; i++) {
                     const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
                     const bool long_record = (pl.h_maxd[lo + i] >> 31) != 0;
                     const uint64_t need = md + md / 8 + 64;
+                    const bool fastb = fast_ok && skx->h_fmt[lo + i] == 1 && pd.leanfail[lo + i] < 2;   // (a block the lean kernel failed twice -- first for its pool, then in the class it was sent to -- stays on the row kernel)
                     int c;
                     if (long_record) c = 5;
-                    else if (need <= cap0) c = 0;
+                    else if (fastb ? (md * 5 / 8 + af.lds_stage_words + 64 <= af.lds_pool_elems) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
                     else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
                     if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c >= 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
                     if (c == 5 && !giant_ok) c = 6;
                     if (c >= 5 && need > gneed) gneed = need;
-                    L[c].push_back(lo + i);
+                    L[(fastb && c <= 4) ? 7 + c : c].push_back(lo + i);
                 }
                 pd.dirty = false; pd.mode = pmode;
                 if (pd.d_lists) { (void)hipFree(pd.d_lists); pd.d_lists = nullptr; }
                 HIPCHK(hipMalloc(&pd.d_lists, (size_t)nblocks * sizeof(uint32_t)));
                 size_t off = 0;
-                for (int c = 0; c < 7; c++) {
+                for (int c = 0; c < 12; c++) {
                     pd.count[c] = (uint32_t)L[c].size();
                     if (!L[c].empty()) HIPCHK(hipMemcpy(pd.d_lists + off, L[c].data(), L[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                     off += L[c].size();
@@ -652,7 +687,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             size_t off = 0;
             DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
             off += pd.count[0];
-            size_t offc[7]; { size_t o = 0; for (int c = 0; c < 7; c++) { offc[c] = o; o += pd.count[c]; } }
+            size_t offc[12]; { size_t o = 0; for (int c = 0; c < 12; c++) { offc[c] = o; o += pd.count[c]; } }
             const bool tier0_first = knob("BVG_ORDER") && atoi(knob("BVG_ORDER")) == 1;
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
@@ -674,15 +709,24 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 launch_rows_any(ac, pd.count[c], g->side[knob("BVG_SIDE6") ? c : 1 + (c & 1)], true);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
                 launches++;
             }
+            for (int c = 4; c >= 1; c--) {                                     // the same classes of the lean scan kernel
+                if (!pd.count[7 + c]) continue;
+                DecodeArgs ac = af; ac.work_list = pd.d_lists + offc[7 + c];
+                ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
+                launch_scan_decode(ac, pd.count[7 + c], g->side[1 + (c & 1)]);
+                launches++;
+            }
+            if (pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], g->stream); launches++; }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
             HIPCHK(hipStreamSynchronize(g->stream));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, g->ev0, g->ev1));
             kernel_ms += ms;
-            if (dbg_on()) fprintf(stderr, "[bvg] tiers concurrent: %u + %u/%u/%u/%u LDS-class + %u giant + %u generic blocks, %.3f ms\n",
-                                             pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], pd.count[6], ms);
-            slow_blocks = nblocks - pd.count[0];
+            if (dbg_on()) fprintf(stderr, "[bvg] tiers concurrent: scan kernel %u + %u/%u/%u/%u LDS-class, row kernel %u + %u/%u/%u/%u LDS-class, %u giant + %u generic blocks, %.3f ms\n",
+                                             pd.count[7], pd.count[8], pd.count[9], pd.count[10], pd.count[11], pd.count[0], pd.count[1], pd.count[2], pd.count[3], pd.count[4], pd.count[5], pd.count[6], ms);
+            slow_blocks = nblocks - pd.count[0] - pd.count[7];
+            lean_blocks = pd.count[7] + pd.count[8] + pd.count[9] + pd.count[10] + pd.count[11];
             predicted_run = true;
             if (ngiant && !gbatch) {                                           // could not get the giant workspace: leave them to the cascade
                 std::vector<uint32_t> gl(ngiant);
@@ -690,6 +734,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 r = fetch_failures(work); if (r) return r;
                 work.insert(work.end(), gl.begin(), gl.end());
             } else { r = fetch_failures(work); if (r) return r; }
+            if (fast_ok) for (uint32_t id : work) if (id < pd.leanfail.size() && skx->h_fmt[id] == 1 && pd.leanfail[id] < 2) { pd.leanfail[id]++; pd.dirty = true; }
             slow_blocks += (uint32_t)work.size();                              // blocks the prediction missed: re-run by the cascade below
         } else {
 #ifdef BVG_EXPERIMENTAL
@@ -805,7 +850,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     }
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
-        res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks;
+        res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks; res->lean_blocks = lean_blocks;
         res->index_bytes = (uint64_t)(to - from + 1) * (sh->offs.lo ? 4 : 8) + (sh->offs.lo ? ((uint64_t)(to - from) >> kOffShift) * 8 : 0) + (uint64_t)nblocks * 20;
         res->index_entries = a.skip_first && skx->h_first.size() > (size_t)lo + nblocks ? skx->h_first[lo + nblocks] - skx->h_first[lo] : 0;
         if (a.skip_first) res->index_bytes += res->index_entries * (2 + esz) + (uint64_t)nblocks * 9;
@@ -1526,7 +1571,7 @@ static int bvg_scan_multi_impl(bvg_graph* const* per_gpu, int ngpu, int balance,
         if (st[(size_t)i]) return st[(size_t)i];
         const bvg_scan_result& x = res[(size_t)i];
         total->nodes += x.nodes; total->arcs += x.arcs; total->chk += x.chk; total->graph_bytes += x.graph_bytes; total->index_bytes += x.index_bytes;
-        total->launches += x.launches; total->slow_blocks += x.slow_blocks; total->index_entries += x.index_entries;
+        total->launches += x.launches; total->slow_blocks += x.slow_blocks; total->index_entries += x.index_entries; total->lean_blocks += x.lean_blocks;
         if (x.kernel_ms > total->kernel_ms) total->kernel_ms = x.kernel_ms;
         if (per_shard) per_shard[i] = x;
     }

@@ -97,6 +97,10 @@ struct DecodeArgs {
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
 // the lean LDS-resident row kernel (bvg_rows.hip): tiers 0 and 1
 void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
+// the lean scan kernel (bvg_scan.hip): validated blocks of a scan, 32-bit successors, default codings, skip index present
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s);
+size_t scan_static_lds();
+
 // Experiments that lost to the row kernel are compiled only by `make experimental` (-DBVG_EXPERIMENTAL): the row kernel
 // with one workgroup of nw wavefronts per block sharing the pool (bvg_rows_wg.hip), the streaming data-flow kernel
 // (bvg_stream.hip), the flow scan kernel (bvg_flow.hip), the chunk-parallel offsets derivation (bvg_derive.hip).

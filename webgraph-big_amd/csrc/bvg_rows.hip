@@ -104,7 +104,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     // residual skip index: entries of this block (sk_n > 0: use them; skip_mode 1/2: count / fill)
     const bool sk_have = a.skip_first != nullptr && !a.batch;
     const uint64_t sk_base = sk_have ? a.skip_first[bid] : 0ull;
-    const bool sk_mine = a.skip_mode != 0 || !a.skip_fmt || a.skip_fmt[bid] == 1;   // (entries filled by the giant kernel have another layout)
+    const bool sk_mine = a.skip_mode != 0 || !a.skip_fmt || a.skip_fmt[bid] == 1 || a.skip_fmt[bid] == 3;   // (entries filled by the giant kernel have another layout)
+    bool validated = true;                                   // skip_mode 2: every row went through the position logic, which refuses what a well-formed stream never holds
     const uint32_t sk_n = sk_have && sk_mine ? (uint32_t)(a.skip_first[bid + 1] - sk_base) : 0u;
     const bool sk_track = a.skip_mode != 0 || sk_n != 0;
     uint32_t sk_run = 0;
@@ -522,7 +523,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             {
                 const uint32_t maxd = wave_max32(emitn ? d : 0u), nlev = wave_max32(emitn ? lvl + 1u : 0u);
                 const uint32_t est = ((rowW * 21u) >> 10) + nlev * a.pass_cost;
-                by_tasks = (est < maxd || (a.dbg & 16u)) && !(a.dbg & 32u);
+                by_tasks = (est < maxd || (a.dbg & 16u) || a.skip_mode == 2) && !(a.dbg & 32u);   // (the index-filling pass is the validating pass: bvg_scan.hip)
             }
             bool zbad = malf;
             if (by_tasks && act && bc) {                                      // copy blocks -> prefix form (MaskPrefix), once per row
@@ -771,6 +772,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             }
         }
         if (!by_tasks) {
+            validated = false;
             produced[lane] = act ? 0u : kInf;
             wave_sync();
             T* const out = pool + base;
@@ -864,7 +866,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
         if (a.skip_mode == 1 && a.skip_cnt) a.skip_cnt[bid] = sk_run;
-        if (a.skip_mode == 2 && a.skip_fmt && sk_have) a.skip_fmt[bid] = 1;
+        if (a.skip_mode == 2 && a.skip_fmt && sk_have) a.skip_fmt[bid] = (TASK && validated && err == 0) ? 1 : 3;   // 1: the lean scan kernel may take the block
         unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
         atomicAdd(&accs[0], (unsigned long long)blk_arcs);
         atomicAdd(&accs[1], (unsigned long long)blk_chk);
