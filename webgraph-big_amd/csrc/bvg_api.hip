@@ -610,21 +610,23 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
                 // queue) + static arrays.  Resident wavefronts per CU step down with it; take the largest even count whose pool
                 // still holds a row's worth of lists (leaves take no pool: about half the row kernel's need).
-                const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64;
-                auto scr_of = [&](uint64_t pe) { return std::max<uint64_t>(320, pe / 5); };
-                auto foot = [&](uint64_t pe) { return ((pe + scr_of(pe)) * 4 + fixed + 127) & ~127ull; };
-                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 26.0;
+                const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 512);   // a super-row: the records that fit it, up to 64
+                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 640;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
+                const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64 + (uint64_t)stagew * 4 + scrw * 4;
+                auto foot = [&](uint64_t pe) { return (pe * 4 + fixed + 127) & ~127ull; };
+                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 14.0;   // window lists + a sub-row's stored lists and parked residuals
                 uint64_t pool = 1024, waves = 4;
-                for (uint64_t w : {20ull, 16ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
-                    if (knob("BVG_SCAN_WAVES") && w != strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) && w != 4) continue;
+                const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
+                for (uint64_t w : {16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
+                    if (wforce && w != wforce && w != 4) continue;
                     uint64_t pw = 8192;
-                    while (pw > 768 && lds_cu / foot(pw) < w) pw -= 32;
-                    if (lds_cu / foot(pw) >= w && ((double)pw >= lists * avg + a.lds_stage_words || w == 4 || knob("BVG_SCAN_WAVES"))) { pool = pw; waves = lds_cu / foot(pw); break; }
+                    while (pw > 512 && lds_cu / foot(pw) < w) pw -= 32;
+                    if (lds_cu / foot(pw) >= w && ((double)pw >= lists * avg || w == 4 || wforce)) { pool = pw; waves = lds_cu / foot(pw); break; }
                 }
                 while (pool + 32 <= 8192 && lds_cu / foot(pool + 32) == waves) pool += 32;
                 if (knob("BVG_SCAN_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(knob("BVG_SCAN_POOL"), nullptr, 10), 512), 12288);
-                af.lds_pool_elems = (uint32_t)pool; af.lds_scr_elems = (uint32_t)scr_of(pool);
-                af.lds_stage_words = std::min<uint32_t>(a.lds_stage_words, 512);
+                af.lds_pool_elems = (uint32_t)pool; af.lds_scr_elems = (uint32_t)scrw;
+                af.lds_stage_words = stagew;
                 if (dbg_on()) fprintf(stderr, "[bvg] scan kernel: pool %u + scratch %u elements, window %u dwords, %llu wavefronts per CU\n", af.lds_pool_elems, af.lds_scr_elems, af.lds_stage_words, (unsigned long long)waves);
             }
         }
@@ -651,7 +653,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     const bool fastb = fast_ok && skx->h_fmt[lo + i] == 1 && pd.leanfail[lo + i] < 2;   // (a block the lean kernel failed twice -- first for its pool, then in the class it was sent to -- stays on the row kernel)
                     int c;
                     if (long_record) c = 5;
-                    else if (fastb ? (md * 5 / 8 + af.lds_stage_words + 64 <= af.lds_pool_elems) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
+                    else if (fastb ? (md / 2 + 64 <= af.lds_pool_elems) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
                     else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
                     if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c >= 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
                     if (c == 5 && !giant_ok) c = 6;
@@ -776,7 +778,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             launches++;
             std::vector<uint32_t> again;
             r = fetch_failures(again); if (r) return r;
-            rest.insert(rest.end(), again.begin(), again.end());
+            // what a class fails is tried in the next larger one (the need a block reported may come from another kernel's footprint)
+            if (c < 3) bins[c + 1].insert(bins[c + 1].end(), again.begin(), again.end()); else rest.insert(rest.end(), again.begin(), again.end());
             if (predicted_run) {                               // remember where the survivors of this class fit
                 bvg_graph::Pred& pd = g->pred;
                 std::sort(again.begin(), again.end());
@@ -844,6 +847,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     HIPCHK(hipMemcpyAsync(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: position steps %llu, position passes %llu, extras passes %llu, rows %llu, position tasks %llu, leaf steps %llu, leaf passes %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[22], acc[23]);
+    if ((a.dbg & 64u) && lean_blocks) fprintf(stderr, "[bvg] scan kernel rows: %llu super-rows, %llu sub-rows, %llu nodes in them\n", acc[5], acc[6], acc[7]);
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
         fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f; leaf pass %.0f (loop %.0f)\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6, acc[20] / 1e6, acc[21] / 1e6);

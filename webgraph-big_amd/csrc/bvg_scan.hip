@@ -37,12 +37,13 @@ using namespace rows;
 #ifndef BVG_SCAN_CHUNK
 #define BVG_SCAN_CHUNK 8
 #endif
+constexpr uint32_t kQueueMin = 48;             // run descriptors the scratch area always keeps room for
 constexpr uint32_t kChunk = BVG_SCAN_CHUNK;    // leaf elements per lane and pass (a kept copy block of a web graph is ~9 elements long)
 
 typedef uint32_t T;
 
 __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool (the stream window lies inside it) | scratch
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint32_t nd_base[kRing];
     __shared__ uint32_t nd_d[kRing];
     __shared__ uint32_t rtmap[128];               // task maps: residual segments -> lanes (two per lane), extras / positions / chunks -> lanes
@@ -59,13 +60,9 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
 
     T* const pool = reinterpret_cast<T*>(dyn_lds);
     T* const scr = pool + a.lds_pool_elems;
-    constexpr uint32_t kAl = 4;                                              // elements per 16 bytes (the window is filled with 16-byte stores)
-    const uint32_t SWE = a.lds_stage_words;                                  // window size in pool elements
-    const uint32_t* stage = reinterpret_cast<const uint32_t*>(pool);
-    uint32_t* stage_w = reinterpret_cast<uint32_t*>(pool);
-    uint32_t stage_off = 0;                                                  // first pool element of the window
-    bool ovl_dirty = false;                                                  // a list of the last row reached into the window
     const uint32_t CAP = a.lds_pool_elems, SCR = a.lds_scr_elems;
+    uint32_t* const stage_w = reinterpret_cast<uint32_t*>(scr + SCR);        // the window over the stream: read by every sub-row of a super-row
+    const uint32_t* const stage = stage_w;
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
@@ -81,6 +78,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     unsigned err = 0;
     bool failed = false;
     uint32_t fail_need = 0xFFFFFFFFu;                        // pool elements that would have been enough (when known)
+    uint32_t cnt_super = 0, cnt_sub = 0, cnt_nodes = 0;      // BVG_DBG & 64: work counters (wave-uniform)
     // -DBVG_PROF builds only (`make prof`): wave-cycles per section, reported with BVG_DBG & 64 through the row kernel's counters
     // {0 descriptors + levels, 1 Z2 sizing, 2 Z2 set-up, 3 Z1, 4 Z2 loop, 5 phase 1, 6 row set-up, 7 headers, 8 pool sizing, 9 residuals, 10 leaf pass, 11 leaf loop}
 #ifdef BVG_PROF
@@ -97,43 +95,49 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     const uint32_t sk_n = (uint32_t)(a.skip_first[bid + 1] - sk_base);
     uint32_t sk_run = 0;
 
+    // keeps only the stored lists of the W nodes before node `upto`, moved to the front of the pool
+    auto compact = [&](int64_t upto) {
+        uint32_t my_d = 0, my_base = 0; const int64_t y = upto - (int64_t)W + (int64_t)lane;
+        const bool livelane = lane < W && y >= hs;
+        if (livelane) { my_base = nd_base[(uint32_t)y & RM]; my_d = my_base == kInf ? 0u : nd_d[(uint32_t)y & RM]; }
+        const uint32_t nincl = wave_incl_scan32(my_d);
+        const uint32_t nbase = nincl - my_d;
+        for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
+            const uint32_t src = lane_get(my_base, jn), dst = lane_get(nbase, jn), len = lane_get(my_d, jn);
+            if (src != dst && len)
+                for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
+        }
+        if (livelane && my_base != kInf) nd_base[(uint32_t)y & RM] = nbase;
+        pool_used = lane_get(nincl, 63);
+        wave_sync();
+    };
+
     int64_t r0 = hs;
-    // offsets of the first row (later rows are prefetched while the previous row is decoded)
+    // offsets of the first super-row (later ones are prefetched while the previous one is decoded)
     uint64_t off_x = 0, rec_end = 0;
     if (r0 + lane < e) { off_x = a.offsets[r0 + lane]; rec_end = a.offsets[r0 + lane + 1]; }
 
-    while (r0 < e) {
-        // ------------------------------------------------------------------ row set-up
+    while (r0 < e && !failed) {
+        // ================================================================== SUPER-ROW: up to 64 nodes, one per lane.  Their records are
+        // parsed once, with every lane busy; the lists are then built in SUB-ROWS of as many nodes as the pool holds.
         const uint32_t tq5 = BVG_T0();
         const int64_t x = r0 + lane;
         const bool in_range = x < e;
         const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
         const uint32_t left = (uint32_t)(e - r0 > 64 ? 64 : e - r0);
-        if (pool_used > 0) {
-            // every row starts from the lists of the last W nodes alone, moved to the front of the pool
-            uint32_t my_d = 0, my_base = 0; const int64_t y = r0 - (int64_t)W + (int64_t)lane;
-            const bool livelane = lane < W && y >= hs;
-            if (livelane) { my_base = nd_base[(uint32_t)y & RM]; my_d = my_base == kInf ? 0u : nd_d[(uint32_t)y & RM]; }
-            const uint32_t nincl = wave_incl_scan32(my_d);
-            const uint32_t nbase = nincl - my_d;
-            for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
-                const uint32_t src = lane_get(my_base, jn), dst = lane_get(nbase, jn), len = lane_get(my_d, jn);
-                if (src != dst)
-                    for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
-            }
-            if (livelane && my_base != kInf) nd_base[(uint32_t)y & RM] = nbase;
-            pool_used = lane_get(nincl, 63);
-            wave_sync();
+        if (pool_used > 0) compact(r0);
+        // Touch what the wavefront will wait for later, so that it comes from L2 instead of HBM: the 2 KiB of stream behind this
+        // super-row's last record (the next super-row's window) and the skip entries of this super-row's long residual lists.  The
+        // values are never used (the mask below is zero); the loads only have to be issued.
+        uint32_t pf = 0;
+        if (a.dbg != 0xFFFFFFFFu) {
+            const uint64_t nb0 = ((lane_get64(rec_end, left - 1) >> 3) & ~127ull) + (uint64_t)lane * 128u;
+            if (lane < 18 && nb0 + 4 <= a.padded_bytes) pf = *reinterpret_cast<const uint32_t*>(a.graph + nb0);
+            if (lane >= 32 && lane < 36) { const uint32_t ix = sk_run + (lane - 32u) * 64u; if (ix < sk_n) pf ^= a.skip_bit[sk_base + ix]; }
+            if (lane >= 40 && lane < 48) { const uint32_t ix = sk_run + (lane - 40u) * 32u; if (ix < sk_n) pf ^= reinterpret_cast<const T*>(a.skip_val)[sk_base + ix]; }
         }
-        {
-            const uint32_t noff = (pool_used + kAl - 1) & ~(kAl - 1);
-            if (noff + SWE > CAP) { failed = true; fail_need = pool_used + SWE + (pool_used >> 2) + 64; break; }   // the window lists leave no room
-            if (noff != stage_off || ovl_dirty) stg_bits = 0;                 // the previous row's lists were written over the window
-            stage_off = noff; ovl_dirty = false;
-            stage_w = reinterpret_cast<uint32_t*>(pool + stage_off); stage = stage_w;
-        }
-        {   // (re)stage the window when this row's records are not covered by it
+        {   // (re)stage the window when this super-row's records are not covered by it
             const uint64_t row_lo = lane_get64(off_x, 0);
             const uint64_t row_hi = lane_get64(rec_end, left - 1);
             if (!(row_lo >= stg_bit0 && row_hi + 96 <= stg_bit0 + stg_bits)) {
@@ -150,44 +154,34 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 wave_sync();
             }
         }
-        // rows are cut where the records stop fitting the window (the next row restages from there)
+        // the super-row is cut where the records stop fitting the window (the next one restages from there)
         const bool inwin = in_range && rec_end + 96 <= stg_bit0 + stg_bits && off_x >= stg_bit0;
-        uint32_t kwin;
+        uint32_t K1;
         {   // contiguous prefix only
             const uint64_t m = ballot(inwin);
-            kwin = m == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~m) - 1u;
-            if (kwin > left) kwin = left;
+            K1 = m == ~0ull ? 64u : (uint32_t)__ffsll((unsigned long long)~m) - 1u;
+            if (K1 > left) K1 = left;
         }
-        if (kwin == 0) { failed = true; fail_need = 0xFFFFFFF1u; break; }      // a single record larger than the window
+        if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF1u; break; }       // a single record larger than the window
         uint32_t rel = (uint32_t)(off_x - stg_bit0);                          // bit cursor relative to the window
         const uint32_t pend = (uint32_t)(rec_end - stg_bit0);
+        const uint32_t recrel = rel;
         bool bad = false;
         uint64_t v;
         uint32_t d = 0;
-        if (needed && lane < kwin) {                                          // readOutdegree, BVG:654-660
+        if (needed && lane < K1) {                                            // readOutdegree, BVG:654-660
             const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
             bad |= l == 0 || v > 0x7FFFFFFFull; rel += l; d = bad ? 0u : (uint32_t)v;
         }
         const uint32_t dclamp = d > CAP ? CAP + 1 : d;
-        const uint32_t incl = wave_incl_scan32(dclamp);
-        const uint32_t avail = CAP - pool_used;
-        // only lists that a later node can copy are stored: the row is first sized optimistically on the outdegrees and cut to what
-        // really fits once the references are known
-        uint32_t k = kwin;
-        {
-            const uint32_t budget = avail * 2u;
-            if (lane_get(incl, 63) > budget) { const uint32_t kf = (uint32_t)__popcll(ballot(incl <= budget)); k = kf < k ? kf : k; }
-            if (k == 0) k = 1;                                                // the exact check follows the header parse
-        }
-        if (needed && lane < k) nd_d[(uint32_t)x & RM] = d;
+        if (needed && lane < K1) nd_d[(uint32_t)x & RM] = d;
         wave_sync();
-
         BVG_T1(6, tq5);
         const uint32_t tq7 = BVG_T0();
-        // ------------------------------------------------------------------ phase 1: parse own record
+        // ------------------------------------------------------------------ phase 1: every lane parses the header of its record
         uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
         int64_t extra = d;
-        const bool parse = needed && lane < k && d > 0;
+        bool parse = needed && lane < K1 && d > 0;
         // ---- A: reference and block count (BVG:1015-1021)
         if (parse) {
             if (W > 0) {                                                      // readReference, BVG:692-703
@@ -203,14 +197,16 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 bad |= l == 0 || v > pend - rel + 1; rel += l; bc = bad ? 0u : (uint32_t)v;
             }
         }
-        const uint32_t bincl = wave_incl_scan32(bc > SCR ? SCR + 1 : bc);
-        { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCR)); k = kb < k ? kb : k; }
-        if (k == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }        // one node's copy blocks exceed the scratch area
+        // the copy blocks and intervals of the super-row go to the scratch area, which must keep kQueueMin run descriptors free
+        const uint32_t SCRH = SCR > 2u * kQueueMin ? SCR - 2u * kQueueMin : 0u;
+        const uint32_t bincl = wave_incl_scan32(bc > SCRH ? SCRH + 1 : bc);
+        { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCRH)); K1 = kb < K1 ? kb : K1; }
+        if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }       // one node's copy blocks exceed the scratch area
         sb = bincl - bc;
-        uint32_t btot = lane_get(bincl, k - 1);
+        uint32_t btot = lane_get(bincl, K1 - 1);
         // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
         uint32_t rlenN = 0;
-        if (parse && lane < k) {
+        if (parse && lane < K1) {
             if (ref > 0) {
                 int64_t copied = 0, tot = 0;
                 for (uint32_t i = 0; i < bc; i++) {
@@ -232,20 +228,21 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 bad |= l == 0 || v > (pend - rel) / 2 + 1; rel += l; ic = bad ? 0u : (uint32_t)v;
             }
         }
-        const uint32_t iw = lane < k ? 2 * ic : 0u;
-        const uint32_t iincl = wave_incl_scan32(iw > SCR ? SCR + 1 : iw);
-        // the copy blocks of the row may have taken the whole area: halve the row until the first node's intervals fit
+        const uint32_t iw = lane < K1 ? 2 * ic : 0u;
+        const uint32_t iincl = wave_incl_scan32(iw > SCRH ? SCRH + 1 : iw);
+        // the copy blocks may have taken the whole area: halve the super-row until the first node's intervals fit
         for (;;) {
-            const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCR));
-            if (ki != 0 || k <= 1) { k = ki < k ? ki : k; break; }
-            k = (k + 1u) >> 1; btot = lane_get(bincl, k - 1);
+            const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCRH));
+            if (ki != 0 || K1 <= 1) { K1 = ki < K1 ? ki : K1; break; }
+            K1 = (K1 + 1u) >> 1; btot = lane_get(bincl, K1 - 1);
         }
-        if (k == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }        // one node's intervals exceed the scratch area
+        if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }       // one node's intervals exceed the scratch area
         ib = btot + iincl - iw;
-        const uint32_t qb = (btot + lane_get(iincl, k - 1) + 1u) & ~1u;       // the run queue follows the blocks and intervals (8-byte entries)
+        const uint32_t qb = (btot + lane_get(iincl, K1 - 1) + 1u) & ~1u;      // the run queue follows the blocks and intervals (8-byte entries)
         const uint32_t qcap = (SCR - qb) >> 1;
+        parse = parse && lane < K1;
         // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals
-        if (parse && lane < k) {
+        if (parse) {
             if (ic > 0) {
                 int64_t prev = 0;
                 for (uint32_t i = 0; i < ic; i++) {
@@ -264,425 +261,430 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             }
             nres = (uint32_t)extra;
         }
+        if (ballot(bad && lane < K1)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
         BVG_T1(7, tq7);
         const uint32_t tq8 = BVG_T0();
-        // ---- pool allocation: the full list (and, parked top-down, its residual values) only if some later node may copy it --
-        //      referenced inside the row, or one of the last W nodes of the row; a leaf takes no pool at all, only run descriptors
+        // ---- which lists are STORED: those that a later node copies from -- referenced inside the super-row (every reference of the
+        //      super-row is known now) or one of its last W nodes, which the next super-row may reference.  Every other node is a leaf:
+        //      no list, no parked residuals, only run descriptors.
+        const bool on1 = needed && lane < K1;
         uint64_t refmask = 0;
-        for (uint32_t r = 1; r <= W && r < 64; r++) refmask |= ballot(parse && lane < k && ref == r) >> r;
-        const bool repn = needed && x >= rep_lo && x < rep_hi;
-        uint32_t size = 0, sincl = 0, rtb = 0, qs = 0, Q = 0;
-        bool stored = true;
-        for (;;) {
-            const uint32_t tailstart = k > W ? k - W : 0;
-            stored = lane >= tailstart || ((refmask >> lane) & 1ull);
-            const bool on = needed && lane < k;
-            size = (on && stored) ? dclamp : 0u;
-            const uint32_t rsz = (on && stored) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // + the guard slot of the position tasks
-            // run descriptors of a leaf that is reported: its kept copy blocks (explicit ones at even indices + the implicit tail when
-            // their number is even, MaskedLongIterator.java:73-78) and its intervals
-            const uint32_t nq = (on && !stored && repn && d > 0) ? (ref > 0 ? ((bc + 2u) >> 1) : 0u) + ic : 0u;
-            sincl = wave_incl_scan32(size);
-            const uint32_t rincl = wave_incl_scan32(rsz);
-            const uint32_t qincl = wave_incl_scan32(nq);
-            rtb = CAP - (rincl > CAP ? CAP : rincl);
-            uint32_t tot = sincl + rincl;
-            if (rincl + stage_off + SWE > CAP) tot = 0xFFFFFFFFu;             // the parked residuals may not reach down into the window
-            if (qincl > qcap) tot = 0xFFFFFFFFu;                              // the run queue is full
-            qs = qincl - nq; Q = lane_get(qincl, k - 1);
-            if (lane_get(tot, k - 1) <= avail) break;
-            const uint32_t kf = (uint32_t)__popcll(ballot(tot <= avail && lane < k));
-            if (kf == 0) { k = 0; break; }
-            k = kf;
-        }
-        if (k == 0) {                                                         // first node alone overflows the pool (or the queue)
-            failed = true;
-            {
-                uint32_t d0 = lane_get(d, 0); const uint32_t n0 = lane_get(nres, 0);
-                if (d0 <= 0x3FFFFFFFu) d0 += (n0 > d0 ? d0 : n0) + 1u;
-                fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64 + SWE;
-            }
-            break;
-        }
-        const bool act = needed && lane < k;
-        const bool rep = act && repn;
-        const uint32_t base = pool_used + (sincl - size);
-        if (act) nd_base[(uint32_t)x & RM] = stored ? base : kInf;            // (a leaf has no list: nothing to compact, nothing to copy from)
-        pool_used += lane_get(sincl, k - 1);
-        if (pool_used > stage_off) ovl_dirty = true;
-        // prefetch the next row's offsets (their latency hides behind the rest of this row's decode)
+        for (uint32_t r = 1; r <= W && r < 64; r++) refmask |= ballot(parse && ref == r) >> r;
+        const bool stored = lane + W >= K1 || ((refmask >> lane) & 1ull);
+        const bool repn = on1 && x >= rep_lo && x < rep_hi;
+        // prefetch the next super-row's offsets (their latency hides behind this one's decode)
         uint64_t nxt_off = 0, nxt_end = 0;
         {
-            const int64_t nx = r0 + k + lane;
+            const int64_t nx = r0 + K1 + lane;
             if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
         }
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
         uint32_t k0 = 0, k1 = 0;
-        if (rep) {
+        if (repn) {
             const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
             k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
         }
         // a stored list without reference is emitted from its parked residuals (they play the referenced list): those are summed
-        // there; every other residual is summed here, at decode time
+        // there; every other residual is summed when it is decoded
         const uint32_t k1d = (stored && ref == 0) ? 0u : k1;
-        BVG_T1(8, tq8);
-        const uint32_t tq9 = BVG_T0();
-        // ---- D2: residuals (ResidualLongIterator, BVG:902-935): summed, and parked for the lists that are stored
-        const uint32_t recrel = (uint32_t)(off_x - stg_bit0);
-        const uint32_t cntE = (parse && lane < k && !bad && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;     // skip entries of the row, in node order
+        // skip entries of the super-row, in node order
+        const uint32_t cntE = (parse && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
         uint32_t efirst;
         {
             const uint32_t eincl = wave_incl_scan32(cntE);
             efirst = sk_run + eincl - cntE;
             sk_run += lane_get(eincl, 63);
         }
-        uint64_t csum = 0;
-        if (sk_n != 0 && ballot(cntE != 0)) {
-            // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task
-            if (sk_run > sk_n) { failed = true; fail_need = 0xFFFFFFF5u; break; }      // index out of step with the stream
-            // long tasks first (full segments and tails of more than kShortTask gaps), the short tails after them: a pass of 64
-            // tasks lasts as long as its longest one, so like goes with like
-            const bool hasres = parse && lane < k && nres > 0 && !bad;
-            const uint32_t lastc = nres - cntE * kSkipEvery;
-            const bool shortt = hasres && lastc <= kShortTask;
-            const uint32_t Tn = hasres ? cntE + (shortt ? 0u : 1u) : 0u;           // long tasks of this node
-            const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
-            const uint64_t smask = ballot(shortt);
-            const uint32_t ss = NL + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull)), Ttot = NL + (uint32_t)__popcll(smask);
-            bool tbad = false;
-            // RU tasks per lane and pass, decoded in one interleaved loop: two independent chains per lane hide each other's LDS latency
-            auto task_passes = [&](auto RUc) {
-            constexpr uint32_t RU = decltype(RUc)::value, RP = 64u * RU;
-            for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
-                {
-                    const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
-                    const uint32_t q1 = ts >= p0 + RP ? 0u : (ts + Tn > p0 + RP ? p0 + RP - ts : Tn);
-                    for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
-                    if (shortt && ss >= p0 && ss < p0 + RP) rtmap[ss - p0] = lane | (cntE << 8);
-                }
-                wave_sync();
-                bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
-#pragma unroll
-                for (uint32_t u = 0; u < RU; u++) {
-                    tl[u] = p0 + 64u * u + lane < Ttot;
-                    const uint32_t ent = tl[u] ? rtmap[64u * u + lane] : lane;
-                    const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
-                    const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
-                    const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? rtb : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
-                    const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
-                    tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
-                    const uint32_t t0 = q * kSkipEvery;
-                    const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
-                    cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
-                    trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)(r0 + nl); tpend[u] = t_pend;
-                    tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
-                    taddr[u] = t_dst == kInf ? kInf : t_dst + t0;
-                    if (tl[u] && q) {
-                        const uint64_t ei = sk_base + t_ef + q - 1u;
-                        trel[u] = t_rec + a.skip_bit[ei]; r[u] = reinterpret_cast<const T*>(a.skip_val)[ei];
-                        if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
-                    }
-                }
-                for (uint32_t i = 0;; i++) {
-                    bool on[RU]; bool any = false;
-#pragma unroll
-                    for (uint32_t u = 0; u < RU; u++) { on[u] = i < cnt[u]; any |= on[u]; }
-                    if (!ballot(any)) break;
-                    uint32_t len[RU]; uint64_t val[RU]; bool slow = false;
-                    uint32_t w32[RU];
-#pragma unroll
-                    for (uint32_t u = 0; u < RU; u++) w32[u] = win32<LIN>(stage, trel[u]);   // all chains' LDS reads first: they overlap
-#pragma unroll
-                    for (uint32_t u = 0; u < RU; u++) {
-                        uint32_t v32 = 0; len[u] = zfast ? zeta_fast32(w32[u], zk, v32) : 0u; val[u] = v32;
-                        slow |= on[u] && len[u] == 0;
-                    }
-                    if (ballot(slow)) {                                   // codes longer than 31 bits (or zeta_1): one rare, wave-uniform detour
-#pragma unroll
-                        for (uint32_t u = 0; u < RU; u++)
-                            if (on[u] && len[u] == 0) {
-                                len[u] = zeta64(win64<LIN>(stage, trel[u]), zk, val[u]);
-                                if (len[u] == 0) { tbad = true; cnt[u] = 0; on[u] = false; }
-                            }
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < RU; u++) {
-                        const T gap = (tfirst[u] && i == 0) ? (T)nat2int64(val[u]) : (T)(1 + (T)val[u]);
-                        const T rn = (T)(r[u] + gap);
-                        const uint32_t tn = trel[u] + len[u];
-                        if (on[u] && taddr[u] != kInf) pool[taddr[u] + i] = rn;
-                        csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
-                        r[u] = on[u] ? rn : r[u]; trel[u] = on[u] ? tn : trel[u];
-                        if (on[u] && tn > tpend[u]) { tbad = true; cnt[u] = 0; }
-                    }
-                }
-                wave_sync();
-            }
-            };
-            if (Ttot > 96u) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
-            bad |= tbad;
-        } else if (parse && lane < k) {
-            if (nres > 0 && !bad) {
-                T r = (T)x;
-                for (uint32_t t = 0; t < nres; t++) {
-                    uint64_t val;
-                    const uint32_t len = read_residual<false>(stage, rel, zfast, zk, a.cod.residual, val);
-                    if (len == 0) { bad = true; break; }
-                    rel += len;
-                    r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
-                    if (stored) pool[rtb + t] = r;
-                    csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
-                    if (rel > pend) { bad = true; break; }
-                }
-            }
-        }
-        blk_chk += csum;
-        if (ballot(bad && lane < k)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
-        wave_sync();
-
-        BVG_T1(9, tq9);
+        if (sk_run > sk_n) { failed = true; fail_need = 0xFFFFFFF5u; break; }   // index out of step with the stream
+        const uint32_t nqn = (on1 && !stored && repn && d > 0) ? (ref > 0 ? ((bc + 2u) >> 1) : 0u) + ic : 0u;   // run descriptors of a leaf: kept copy blocks
+                                                                                 // (the explicit ones at even indices + the implicit tail when their number is even, MaskedLongIterator.java:73-78) and intervals
+        BVG_T1(8, tq8);
         BVG_T1(5, tq5);
-        const uint32_t tq0 = BVG_T0();
-        // ------------------------------------------------------------------ phase 2
-        uint32_t* const tmap = rtmap + 64;
-        constexpr uint32_t HS = 16;                                           // interval entry: length | position << HS
-        const T HM = (T)0xFFFFu;
-        uint32_t rlbN = 0;
-        if (act && ref > 0) rlbN = nd_base[(uint32_t)(x - ref) & RM];
-        // A stored node without reference is its residuals merged with its intervals (BVG:1087-1089): the parked residual values play
-        // the role of an unmasked "referenced list", the intervals are the only extras to place (and the guard serves as its
-        // empty array of residual positions).
-        const bool pure = act && ref == 0;
-        if (pure) { rlbN = rtb; rlenN = nres; }
-        const uint32_t rtbN = pure ? rtb + nres : rtb, nresN = pure ? 0u : nres;
-        const bool emitn = act && d > 0;
-        // ---- run descriptors of the leaves {lo = first pool element of the run | first value of the interval, hi = length | node lane
-        //      << 24 | interval << 31}; copy blocks of the stored nodes -> prefix form (MaskPrefix)
-        {
-            uint64_t* const queue = reinterpret_cast<uint64_t*>(scr + qb);
-            const bool leaf = emitn && !stored && rep;
-            if (emitn && ref > 0 && (stored || leaf)) {
-                uint32_t pp = 0, kk = 0, slot = qs;
-                const uint32_t tag = (uint32_t)lane << 24;
-                for (uint32_t i = 0; i < bc; i++) {
-                    const uint32_t b = (uint32_t)scr[sb + i];
-                    if (stored) { pp += b; if (!(i & 1u)) kk += b; scr[sb + i] = MaskPrefix<T>::pack(pp, kk); }
-                    else {
-                        if (!(i & 1u)) { queue[slot] = (uint64_t)(rlbN + pp) | ((uint64_t)(b | tag) << 32); slot++; }
-                        pp += b;
-                    }
-                }
-                if (!stored && !(bc & 1u)) { queue[slot] = (uint64_t)(rlbN + pp) | ((uint64_t)((rlenN - pp) | tag) << 32); slot++; }
+
+        // ================================================================== SUB-ROWS [sa, se) of the super-row
+        cnt_super++; cnt_nodes += K1;
+        uint32_t sa = 0;
+        while (sa < K1) {
+            const uint32_t tq8b = BVG_T0();
+            const uint32_t avail = CAP - pool_used;
+            const bool cand = on1 && lane >= sa;
+            const uint32_t size = (cand && stored) ? dclamp : 0u;
+            const uint32_t rsz = (cand && stored) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
+            const uint32_t nq = lane >= sa ? nqn : 0u;
+            const uint32_t sincl = wave_incl_scan32(size), rincl = wave_incl_scan32(rsz), qincl = wave_incl_scan32(nq);
+            const bool fits = lane >= sa && lane < K1 && (uint64_t)sincl + rincl <= avail && qincl <= qcap;
+            const uint32_t se = sa + (uint32_t)__popcll(ballot(fits));          // (the sums are prefixes: `fits` is a contiguous run from sa)
+            if (se == sa) {                                                   // the first node alone overflows the pool (or the queue)
+                failed = true;
+                uint32_t d0 = lane_get(d, sa); const uint32_t n0 = lane_get(nres, sa);
+                if (d0 <= 0x3FFFFFFFu) d0 += (n0 > d0 ? d0 : n0) + 1u;
+                fail_need = d0 > 0x3FFFFFFFu ? 0xFFFFFFF2u : d0 + pool_used + (d0 >> 2) + 64;
+                break;
             }
-            if (leaf && ic) {
-                uint32_t slot = qs + (ref > 0 ? ((bc + 2u) >> 1) : 0u);
-                const uint32_t tag = ((uint32_t)lane << 24) | 0x80000000u;
-                for (uint32_t i = 0; i < ic; i++) { queue[slot] = (uint64_t)scr[ib + 2 * i] | ((uint64_t)((uint32_t)scr[ib + 2 * i + 1] | tag) << 32); slot++; }
-            }
-        }
-        // ---- level-synchronous emission by POSITION of the stored lists (as in bvg_rows.hip; no overlap checks: validated)
-        const bool inrow = act && ref > 0 && ref <= lane;
-        uint32_t lvl = 0;
-        for (int it = 0; it < 64; it++) {
-            const uint32_t up = __shfl(lvl, inrow ? (int)(lane - ref) : (int)lane, 64);
-            const uint32_t nl = inrow ? up + 1 : 0;
-            const bool ch = nl != lvl; lvl = nl;
-            if (!ballot(ch)) break;
-        }
-        const bool emits = emitn && stored;
-        if (emits) pool[rtb + nres] = sentinel<T>();                          // guard behind the node's residual positions
-        uint64_t remaining = ballot(emits);
-        wave_sync();
-        BVG_T1(0, tq0);
-        for (uint32_t L = 0; remaining; L++) {
-            const bool mem = emits && lvl == L;
-            remaining &= ~ballot(mem);
-            if (!ballot(mem)) continue;
-            // ---------------- Z1: one lane per extra: its output position = (extras below it) + (copied elements below it)
-            const uint32_t tq3 = BVG_T0();
-            {
-                const uint32_t In = mem ? nresN + ic : 0u;
-                const uint32_t iincl2 = wave_incl_scan32(In), is = iincl2 - In, Itot = lane_get(iincl2, 63);
-                for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
+            cnt_sub++;
+            const bool act = cand && lane < se;
+            const bool rep = act && repn;
+            const uint32_t base = pool_used + (sincl - size);
+            const uint32_t rtb = CAP - (rincl > CAP ? CAP : rincl);
+            const uint32_t qs = qincl - nq, Q = lane_get(qincl, se - 1);
+            if (act) nd_base[(uint32_t)x & RM] = stored ? base : kInf;        // (a leaf has no list: nothing to compact, nothing to copy from)
+            pool_used += lane_get(sincl, se - 1);
+            BVG_T1(8, tq8b);
+            const uint32_t tq9 = BVG_T0();
+            // ---- D2: residuals (ResidualLongIterator, BVG:902-935): summed, and parked for the lists that are stored
+            const bool rparse = parse && act;
+            uint64_t csum = 0;
+            if (sk_n != 0 && ballot(rparse && cntE != 0)) {
+                // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task.  Long tasks first
+                // (full segments and tails of more than kShortTask gaps), the short tails after them: a pass of 64 tasks lasts as long
+                // as its longest one, so like goes with like
+                const bool hasres = rparse && nres > 0;
+                const uint32_t ce = hasres ? cntE : 0u;
+                const uint32_t lastc = nres - ce * kSkipEvery;
+                const bool shortt = hasres && lastc <= kShortTask;
+                const uint32_t Tn = hasres ? ce + (shortt ? 0u : 1u) : 0u;            // long tasks of this node
+                const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
+                const uint64_t smask = ballot(shortt);
+                const uint32_t ss = NL + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull)), Ttot = NL + (uint32_t)__popcll(smask);
+                bool tbad = false;
+                // RU tasks per lane and pass, decoded in one interleaved loop: two independent chains per lane hide each other's LDS latency
+                auto task_passes = [&](auto RUc) {
+                constexpr uint32_t RU = decltype(RUc)::value, RP = 64u * RU;
+                for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
                     {
-                        const uint32_t q0 = is < p0 ? p0 - is : 0u;
-                        const uint32_t q1 = is >= p0 + 64u ? 0u : (is + In > p0 + 64u ? p0 + 64u - is : In);
-                        for (uint32_t q = q0; q < q1; q++) tmap[is + q - p0] = lane | (q << 8);
+                        const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
+                        const uint32_t q1 = ts >= p0 + RP ? 0u : (ts + Tn > p0 + RP ? p0 + RP - ts : Tn);
+                        for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
+                        if (shortt && ss >= p0 && ss < p0 + RP) rtmap[ss - p0] = lane | (ce << 8);
                     }
                     wave_sync();
-                    const bool tl = p0 + lane < Itot;
+                    bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
+#pragma unroll
+                    for (uint32_t u = 0; u < RU; u++) {
+                        tl[u] = p0 + 64u * u + lane < Ttot;
+                        const uint32_t ent = tl[u] ? rtmap[64u * u + lane] : lane;
+                        const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                        const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
+                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? rtb : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
+                        const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
+                        tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
+                        const uint32_t t0 = q * kSkipEvery;
+                        const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
+                        cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
+                        trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)(r0 + nl); tpend[u] = t_pend;
+                        tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
+                        taddr[u] = t_dst == kInf ? kInf : t_dst + t0;
+                        if (tl[u] && q) {
+                            const uint64_t ei = sk_base + t_ef + q - 1u;
+                            trel[u] = t_rec + a.skip_bit[ei]; r[u] = reinterpret_cast<const T*>(a.skip_val)[ei];
+                            if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
+                        }
+                    }
+                    for (uint32_t i = 0;; i++) {
+                        bool on[RU]; bool any = false;
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) { on[u] = i < cnt[u]; any |= on[u]; }
+                        if (!ballot(any)) break;
+                        uint32_t len[RU]; uint64_t val[RU]; bool slow = false;
+                        uint32_t w32[RU];
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) w32[u] = win32<LIN>(stage, trel[u]);   // all chains' LDS reads first: they overlap
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) {
+                            uint32_t v32 = 0; len[u] = zfast ? zeta_fast32(w32[u], zk, v32) : 0u; val[u] = v32;
+                            slow |= on[u] && len[u] == 0;
+                        }
+                        if (ballot(slow)) {                                   // codes longer than 31 bits (or zeta_1): one rare, wave-uniform detour
+#pragma unroll
+                            for (uint32_t u = 0; u < RU; u++)
+                                if (on[u] && len[u] == 0) {
+                                    len[u] = zeta64(win64<LIN>(stage, trel[u]), zk, val[u]);
+                                    if (len[u] == 0) { tbad = true; cnt[u] = 0; on[u] = false; }
+                                }
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) {
+                            const T gap = (tfirst[u] && i == 0) ? (T)nat2int64(val[u]) : (T)(1 + (T)val[u]);
+                            const T rn = (T)(r[u] + gap);
+                            const uint32_t tn = trel[u] + len[u];
+                            if (on[u] && taddr[u] != kInf) pool[taddr[u] + i] = rn;
+                            csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
+                            r[u] = on[u] ? rn : r[u]; trel[u] = on[u] ? tn : trel[u];
+                            if (on[u] && tn > tpend[u]) { tbad = true; cnt[u] = 0; }
+                        }
+                    }
+                    wave_sync();
+                }
+                };
+                if (Ttot > 96u) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
+                bad |= tbad;
+            } else if (rparse) {
+                if (nres > 0) {
+                    T r = (T)x;
+                    uint32_t rr = rel;
+                    for (uint32_t t = 0; t < nres; t++) {
+                        uint64_t val;
+                        const uint32_t len = read_residual<false>(stage, rr, zfast, zk, a.cod.residual, val);
+                        if (len == 0) { bad = true; break; }
+                        rr += len;
+                        r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
+                        if (stored) pool[rtb + t] = r;
+                        csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
+                        if (rr > pend) { bad = true; break; }
+                    }
+                }
+            }
+            blk_chk += csum;
+            if (ballot(bad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
+            wave_sync();
+            BVG_T1(9, tq9);
+            BVG_T1(5, tq8b);
+            const uint32_t tq0 = BVG_T0();
+
+            // ------------------------------------------------------------------ phase 2 of the sub-row
+            uint32_t* const tmap = rtmap + 64;
+            constexpr uint32_t HS = 16;                                       // interval entry: length | position << HS
+            const T HM = (T)0xFFFFu;
+            uint32_t rlbN = 0, rlenS = rlenN;
+            if (act && ref > 0) rlbN = nd_base[(uint32_t)(x - ref) & RM];
+            // A stored node without reference is its residuals merged with its intervals (BVG:1087-1089): the parked residual values
+            // play the role of an unmasked "referenced list", the intervals are the only extras to place (and the guard serves as its
+            // empty array of residual positions).
+            const bool pure = act && ref == 0;
+            if (pure) { rlbN = rtb; rlenS = nres; }
+            const uint32_t rtbN = pure ? rtb + nres : rtb, nresN = pure ? 0u : nres;
+            const bool emitn = act && d > 0;
+            // ---- run descriptors of the leaves {lo = first pool element of the run | first value of the interval, hi = length | node lane
+            //      << 24 | interval << 31}; copy blocks of the stored nodes -> prefix form (MaskPrefix)
+            {
+                uint64_t* const queue = reinterpret_cast<uint64_t*>(scr + qb);
+                const bool leaf = emitn && !stored && rep;
+                if (emitn && ref > 0 && (stored || leaf)) {
+                    uint32_t pp = 0, kk = 0, slot = qs;
+                    const uint32_t tag = (uint32_t)lane << 24;
+                    for (uint32_t i = 0; i < bc; i++) {
+                        const uint32_t b = (uint32_t)scr[sb + i];
+                        if (stored) { pp += b; if (!(i & 1u)) kk += b; scr[sb + i] = MaskPrefix<T>::pack(pp, kk); }
+                        else {
+                            if (!(i & 1u)) { queue[slot] = (uint64_t)(rlbN + pp) | ((uint64_t)(b | tag) << 32); slot++; }
+                            pp += b;
+                        }
+                    }
+                    if (!stored && !(bc & 1u)) { queue[slot] = (uint64_t)(rlbN + pp) | ((uint64_t)((rlenS - pp) | tag) << 32); slot++; }
+                }
+                if (leaf && ic) {
+                    uint32_t slot = qs + (ref > 0 ? ((bc + 2u) >> 1) : 0u);
+                    const uint32_t tag = ((uint32_t)lane << 24) | 0x80000000u;
+                    for (uint32_t i = 0; i < ic; i++) { queue[slot] = (uint64_t)scr[ib + 2 * i] | ((uint64_t)((uint32_t)scr[ib + 2 * i + 1] | tag) << 32); slot++; }
+                }
+            }
+            // ---- level-synchronous emission by POSITION of the stored lists (as in bvg_rows.hip; no overlap checks: validated)
+            const bool inrow = act && ref > 0 && ref + sa <= lane;                // the referenced list belongs to this sub-row
+            uint32_t lvl = 0;
+            for (int it = 0; it < 64; it++) {
+                const uint32_t up = __shfl(lvl, inrow ? (int)(lane - ref) : (int)lane, 64);
+                const uint32_t nl = inrow ? up + 1 : 0;
+                const bool ch = nl != lvl; lvl = nl;
+                if (!ballot(ch)) break;
+            }
+            const bool emits = emitn && stored;
+            if (emits) pool[rtb + nres] = sentinel<T>();                      // guard behind the node's residual positions
+            uint64_t remaining = ballot(emits);
+            wave_sync();
+            BVG_T1(0, tq0);
+            for (uint32_t L = 0; remaining; L++) {
+                const bool mem = emits && lvl == L;
+                remaining &= ~ballot(mem);
+                if (!ballot(mem)) continue;
+                // ---------------- Z1: one lane per extra: its output position = (extras below it) + (copied elements below it)
+                const uint32_t tq3 = BVG_T0();
+                {
+                    const uint32_t In = mem ? nresN + ic : 0u;
+                    const uint32_t iincl2 = wave_incl_scan32(In), is = iincl2 - In, Itot = lane_get(iincl2, 63);
+                    for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
+                        {
+                            const uint32_t q0 = is < p0 ? p0 - is : 0u;
+                            const uint32_t q1 = is >= p0 + 64u ? 0u : (is + In > p0 + 64u ? p0 + 64u - is : In);
+                            for (uint32_t q = q0; q < q1; q++) tmap[is + q - p0] = lane | (q << 8);
+                        }
+                        wave_sync();
+                        const bool tl = p0 + lane < Itot;
+                        const uint32_t ent = tl ? tmap[lane] : lane;
+                        const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                        const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenS, nl, 64);
+                        const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
+                        const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
+                        const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
+                        T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false;
+                        if (tl) {
+                            uint32_t eb;
+                            if (q < t_ic) {                                   // interval q: the intervals and residuals below it
+                                isiv = true;
+                                vv = scr[t_ib + 2 * q]; len = (uint32_t)(scr[t_ib + 2 * q + 1] & HM);
+                                eb = 0;
+                                for (uint32_t i = 0; i < q; i++) eb += (uint32_t)(scr[t_ib + 2 * i + 1] & HM);
+                                eb += lds_lower_bound<T>(rt, t_nres, vv);
+                            } else {                                          // residual q - ic
+                                const uint32_t i = q - t_ic;
+                                vv = rt[i]; eb = i;
+                                for (uint32_t kk = 0; kk < t_ic; kk++) {
+                                    const T leftv = scr[t_ib + 2 * kk]; const uint32_t ln = (uint32_t)(scr[t_ib + 2 * kk + 1] & HM);
+                                    if (leftv <= vv) eb += ln;
+                                }
+                            }
+                            uint32_t t = 0;
+                            if (t_rlen) {                                     // copied elements below v: rank of its lower bound under the mask
+                                const uint32_t qq = lds_lower_bound<T>(rl, t_rlen, vv);
+                                uint32_t qn;
+                                t = MaskPrefix<T>::rank(scr + t_sb, t_bc, t_rlen, qq, qn);
+                            }
+                            pe = eb + t;
+                            if (pe + len > t_d) { pe = 0; len = 0; }          // (cannot happen in a validated block; never write outside the list)
+                        }
+                        wave_sync();                                      // the parked values have been read: positions may replace them
+                        if (tl && len) {
+                            if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
+                            else { pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
+                        }
+                        wave_sync();
+                    }
+                }
+                BVG_T1(3, tq3);
+                const uint32_t tq1 = BVG_T0();
+                // ---------------- Z2: tasks of S output positions, all equally long
+                const uint32_t Wl = wave_sum32(mem ? d : 0u);
+                uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
+                uint32_t Tn = 0;
+                for (int it = 0; it < 6; it++) {
+                    Tn = 0;
+                    if (mem) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
+                    const uint32_t tt = wave_sum32(Tn);
+                    if (tt <= 64u || it == 5) break;
+                    const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
+                    S = s2 > S ? s2 : S + 1u;
+                }
+                const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+                BVG_T1(1, tq1);
+                for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+                    const uint32_t tq2 = BVG_T0();
+                    {   // task map of this pass: (node lane, task index inside the node)
+                        const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
+                        const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
+                        for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
+                    }
+                    wave_sync();
+                    const bool tl = p0 + lane < Ttot;
                     const uint32_t ent = tl ? tmap[lane] : lane;
                     const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
-                    const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64);
+                    const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenS, nl, 64);
                     const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                     const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
-                    const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
-                    T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false;
+                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                    const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
+                    uint32_t p = 0, pstop = 0, ri = 0, rnext = kInf, ivk = t_ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = t_bc;
+                    T ivleft = 0;
                     if (tl) {
-                        uint32_t eb;
-                        if (q < t_ic) {                                   // interval q: the intervals and residuals below it
-                            isiv = true;
-                            vv = scr[t_ib + 2 * q]; len = (uint32_t)(scr[t_ib + 2 * q + 1] & HM);
-                            eb = 0;
-                            for (uint32_t i = 0; i < q; i++) eb += (uint32_t)(scr[t_ib + 2 * i + 1] & HM);
-                            eb += lds_lower_bound<T>(rt, t_nres, vv);
-                        } else {                                          // residual q - ic
-                            const uint32_t i = q - t_ic;
-                            vv = rt[i]; eb = i;
-                            for (uint32_t kk = 0; kk < t_ic; kk++) {
-                                const T leftv = scr[t_ib + 2 * kk]; const uint32_t ln = (uint32_t)(scr[t_ib + 2 * kk + 1] & HM);
-                                if (leftv <= vv) eb += ln;
+                        p = q * S; pstop = p + S < t_d ? p + S : t_d;
+                        ri = lds_lower_bound<T>(rt, t_nres, (T)p);            // residual positions below p
+                        rnext = (uint32_t)rt[ri];                             // (the guard reads as kInf)
+                        uint32_t ie = 0;
+                        for (uint32_t i = 0; i < t_ic; i++) {                 // interval elements below p; the interval at / after p
+                            const T pk = scr[t_ib + 2 * i + 1];
+                            const uint32_t ln = (uint32_t)(pk & HM), ps = (uint32_t)(pk >> HS);
+                            if (ps + ln > p) { ivk = i; ivpos = ps; ivlen = ln; ivleft = scr[t_ib + 2 * i]; if (p > ps) ie += p - ps; break; }
+                            ie += ln;
+                        }
+                        const uint32_t t = p - ri - ie;                       // rank of the next copied element among the kept ones
+                        if (t_rlen) MaskPrefix<T>::select(scr + t_sb, t_bc, t_rlen, t, qcur, krem, bi);   // MaskedLongIterator.java:73-100: the t-th kept position
+                    }
+                    const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
+                    uint64_t zsum = 0;
+                    BVG_T1(2, tq2);
+                    const uint32_t tq4 = BVG_T0();
+                    for (;;) {
+                        const bool todo = p < pstop;
+                        if (!ballot(todo)) break;
+                        if (todo) {
+                            if (p == rnext) { ri++; rnext = (uint32_t)rt[ri]; }           // a residual: placed by Z1 (and summed when it was decoded)
+                            else {
+                                const uint32_t io = p - ivpos;
+                                const bool ii = io < ivlen;                               // LongIntervalSequenceIterator.java:71-78
+                                const T cv = rl[qcur < rlast ? qcur : rlast];
+                                const T vv = ii ? (T)(ivleft + (T)io) : cv;
+                                out[p] = vv;
+                                zsum += mix_node<T>(t_k0, t_k1, vv, nb_lo, nbz);
+                                if (ii) {
+                                    if (io + 1u == ivlen) {
+                                        ivk++; ivpos = kInf; ivlen = 0;
+                                        if (ivk < t_ic) { const T pk = scr[t_ib + 2 * ivk + 1]; ivlen = (uint32_t)(pk & HM); ivpos = (uint32_t)(pk >> HS); ivleft = scr[t_ib + 2 * ivk]; }
+                                    }
+                                } else {
+                                    qcur++;
+                                    if (--krem == 0) MaskPrefix<T>::next_block(scr + t_sb, t_bc, t_rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
+                                }
                             }
+                            p++;
                         }
-                        uint32_t t = 0;
-                        if (t_rlen) {                                     // copied elements below v: rank of its lower bound under the mask
-                            const uint32_t qq = lds_lower_bound<T>(rl, t_rlen, vv);
-                            uint32_t qn;
-                            t = MaskPrefix<T>::rank(scr + t_sb, t_bc, t_rlen, qq, qn);
-                        }
-                        pe = eb + t;
-                        if (pe + len > t_d) { pe = 0; len = 0; }          // (cannot happen in a validated block; never write outside the list)
                     }
-                    wave_sync();                                      // the parked values have been read: positions may replace them
-                    if (tl && len) {
-                        if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
-                        else { pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
+                    blk_chk += zsum;
+                    wave_sync();
+                    BVG_T1(4, tq4);
+                }
+            }
+            // ---------------- leaf pass: the run queue, cut into chunks of kChunk elements dealt to all lanes.  Every referenced list
+            // is complete by now.  A chunk is straight-line work: 4 elements per step, their LDS reads issued together.
+            const uint32_t tqL = BVG_T0();
+            for (uint32_t d0 = 0; d0 < Q; d0 += 64) {
+                const uint64_t* const queue = reinterpret_cast<const uint64_t*>(scr + qb);
+                const bool dl = d0 + lane < Q;
+                const uint64_t ent = dl ? queue[d0 + lane] : 0ull;
+                const uint32_t e_lo = (uint32_t)ent, e_hi = (uint32_t)(ent >> 32);
+                const uint32_t e_len = e_hi & 0xFFFFFFu;
+                const uint32_t nch = (e_len + kChunk - 1u) / kChunk;
+                const uint32_t cincl = wave_incl_scan32(nch), cs = cincl - nch, Ctot = lane_get(cincl, 63);
+                const uint32_t e_k0 = __shfl(k0, (int)((e_hi >> 24) & 63u), 64), e_k1 = __shfl(k1, (int)((e_hi >> 24) & 63u), 64);
+                for (uint32_t p0 = 0; p0 < Ctot; p0 += 64) {
+                    {
+                        const uint32_t q0 = cs < p0 ? p0 - cs : 0u;
+                        const uint32_t q1 = cs >= p0 + 64u ? 0u : (cs + nch > p0 + 64u ? p0 + 64u - cs : nch);
+                        for (uint32_t q = q0; q < q1; q++) tmap[cs + q - p0] = lane | (q << 8);
                     }
+                    wave_sync();
+                    const bool tl = p0 + lane < Ctot;
+                    const uint32_t te = tl ? tmap[lane] : lane;
+                    const int sl = (int)(te & 63u); const uint32_t q = te >> 8;
+                    const uint32_t c_lo = __shfl(e_lo, sl, 64), c_hi = __shfl(e_hi, sl, 64);
+                    const uint32_t c_k0 = __shfl(e_k0, sl, 64), c_k1 = __shfl(e_k1, sl, 64);
+                    const uint32_t c_len = c_hi & 0xFFFFFFu, o = q * kChunk;
+                    const uint32_t n = tl ? (c_len - o < kChunk ? c_len - o : kChunk) : 0u;
+                    const bool iota = (c_hi >> 31) != 0u;
+                    const uint32_t b0 = c_lo + o;                              // first pool element / first value of the chunk
+                    const T* const src = pool + (iota ? 0u : b0);
+                    uint64_t lsum = 0;
+                    const uint32_t nmax = wave_max32(n);
+                    const uint32_t tqL2 = BVG_T0();
+                    for (uint32_t i = 0; i < nmax; i += 4) {
+                        const T v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];   // (reads past a run stay inside the LDS allocation)
+                        lsum += mix_node<T>(c_k0, i < n ? c_k1 : 0u, iota ? (T)(b0 + i) : v0, nb_lo, nbz);
+                        lsum += mix_node<T>(c_k0, i + 1 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 1) : v1, nb_lo, nbz);
+                        lsum += mix_node<T>(c_k0, i + 2 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 2) : v2, nb_lo, nbz);
+                        lsum += mix_node<T>(c_k0, i + 3 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 3) : v3, nb_lo, nbz);
+                    }
+                    blk_chk += lsum;
+                    BVG_T1(11, tqL2);
                     wave_sync();
                 }
             }
-            BVG_T1(3, tq3);
-            const uint32_t tq1 = BVG_T0();
-            // ---------------- Z2: tasks of S output positions, all equally long
-            const uint32_t Wl = wave_sum32(mem ? d : 0u);
-            uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
-            uint32_t Tn = 0;
-            for (int it = 0; it < 6; it++) {
-                Tn = 0;
-                if (mem) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
-                const uint32_t tt = wave_sum32(Tn);
-                if (tt <= 64u || it == 5) break;
-                const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
-                S = s2 > S ? s2 : S + 1u;
-            }
-            const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
-            BVG_T1(1, tq1);
-            for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
-                const uint32_t tq2 = BVG_T0();
-                {   // task map of this pass: (node lane, task index inside the node)
-                    const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
-                    const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
-                    for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
-                }
-                wave_sync();
-                const bool tl = p0 + lane < Ttot;
-                const uint32_t ent = tl ? tmap[lane] : lane;
-                const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
-                const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64);
-                const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
-                const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
-                const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
-                const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
-                uint32_t p = 0, pstop = 0, ri = 0, rnext = kInf, ivk = t_ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = t_bc;
-                T ivleft = 0;
-                if (tl) {
-                    p = q * S; pstop = p + S < t_d ? p + S : t_d;
-                    ri = lds_lower_bound<T>(rt, t_nres, (T)p);            // residual positions below p
-                    rnext = (uint32_t)rt[ri];                             // (the guard reads as kInf)
-                    uint32_t ie = 0;
-                    for (uint32_t i = 0; i < t_ic; i++) {                 // interval elements below p; the interval at / after p
-                        const T pk = scr[t_ib + 2 * i + 1];
-                        const uint32_t ln = (uint32_t)(pk & HM), ps = (uint32_t)(pk >> HS);
-                        if (ps + ln > p) { ivk = i; ivpos = ps; ivlen = ln; ivleft = scr[t_ib + 2 * i]; if (p > ps) ie += p - ps; break; }
-                        ie += ln;
-                    }
-                    const uint32_t t = p - ri - ie;                       // rank of the next copied element among the kept ones
-                    if (t_rlen) MaskPrefix<T>::select(scr + t_sb, t_bc, t_rlen, t, qcur, krem, bi);   // MaskedLongIterator.java:73-100: the t-th kept position
-                }
-                const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
-                uint64_t zsum = 0;
-                BVG_T1(2, tq2);
-                const uint32_t tq4 = BVG_T0();
-                for (;;) {
-                    const bool todo = p < pstop;
-                    if (!ballot(todo)) break;
-                    if (todo) {
-                        if (p == rnext) { ri++; rnext = (uint32_t)rt[ri]; }           // a residual: placed by Z1 (and summed when it was decoded)
-                        else {
-                            const uint32_t io = p - ivpos;
-                            const bool ii = io < ivlen;                               // LongIntervalSequenceIterator.java:71-78
-                            const T cv = rl[qcur < rlast ? qcur : rlast];
-                            const T vv = ii ? (T)(ivleft + (T)io) : cv;
-                            out[p] = vv;
-                            zsum += mix_node<T>(t_k0, t_k1, vv, nb_lo, nbz);
-                            if (ii) {
-                                if (io + 1u == ivlen) {
-                                    ivk++; ivpos = kInf; ivlen = 0;
-                                    if (ivk < t_ic) { const T pk = scr[t_ib + 2 * ivk + 1]; ivlen = (uint32_t)(pk & HM); ivpos = (uint32_t)(pk >> HS); ivleft = scr[t_ib + 2 * ivk]; }
-                                }
-                            } else {
-                                qcur++;
-                                if (--krem == 0) MaskPrefix<T>::next_block(scr + t_sb, t_bc, t_rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
-                            }
-                        }
-                        p++;
-                    }
-                }
-                blk_chk += zsum;
-                wave_sync();
-                BVG_T1(4, tq4);
-            }
+            BVG_T1(10, tqL);
+            if (rep) { blk_arcs += d; blk_nodes += 1; }
+            wave_sync();
+            sa = se;
+            if (sa < K1) compact(r0 + (int64_t)sa);                            // the next sub-row starts from the stored lists of the W nodes before it
         }
-        // ---------------- leaf pass: the run queue, cut into chunks of kChunk elements dealt to all lanes.  Every referenced list is
-        // complete by now.  A chunk is straight-line work: 4 elements per step, their LDS reads issued together.
-        const uint32_t tqL = BVG_T0();
-        for (uint32_t d0 = 0; d0 < Q; d0 += 64) {
-            const uint64_t* const queue = reinterpret_cast<const uint64_t*>(scr + qb);
-            const bool dl = d0 + lane < Q;
-            const uint64_t ent = dl ? queue[d0 + lane] : 0ull;
-            const uint32_t e_lo = (uint32_t)ent, e_hi = (uint32_t)(ent >> 32);
-            const uint32_t e_len = e_hi & 0xFFFFFFu;
-            const uint32_t nch = (e_len + kChunk - 1u) / kChunk;
-            const uint32_t cincl = wave_incl_scan32(nch), cs = cincl - nch, Ctot = lane_get(cincl, 63);
-            const uint32_t e_k0 = __shfl(k0, (int)((e_hi >> 24) & 63u), 64), e_k1 = __shfl(k1, (int)((e_hi >> 24) & 63u), 64);
-            for (uint32_t p0 = 0; p0 < Ctot; p0 += 64) {
-                {
-                    const uint32_t q0 = cs < p0 ? p0 - cs : 0u;
-                    const uint32_t q1 = cs >= p0 + 64u ? 0u : (cs + nch > p0 + 64u ? p0 + 64u - cs : nch);
-                    for (uint32_t q = q0; q < q1; q++) tmap[cs + q - p0] = lane | (q << 8);
-                }
-                wave_sync();
-                const bool tl = p0 + lane < Ctot;
-                const uint32_t te = tl ? tmap[lane] : lane;
-                const int sl = (int)(te & 63u); const uint32_t q = te >> 8;
-                const uint32_t c_lo = __shfl(e_lo, sl, 64), c_hi = __shfl(e_hi, sl, 64);
-                const uint32_t c_k0 = __shfl(e_k0, sl, 64), c_k1 = __shfl(e_k1, sl, 64);
-                const uint32_t c_len = c_hi & 0xFFFFFFu, o = q * kChunk;
-                const uint32_t n = tl ? (c_len - o < kChunk ? c_len - o : kChunk) : 0u;
-                const bool iota = (c_hi >> 31) != 0u;
-                const uint32_t b0 = c_lo + o;                              // first pool element / first value of the chunk
-                const T* const src = pool + (iota ? 0u : b0);
-                uint64_t lsum = 0;
-                const uint32_t nmax = wave_max32(n);
-                const uint32_t tqL2 = BVG_T0();
-                for (uint32_t i = 0; i < nmax; i += 4) {
-                    const T v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];   // (reads past a run stay inside the LDS allocation)
-                    lsum += mix_node<T>(c_k0, i < n ? c_k1 : 0u, iota ? (T)(b0 + i) : v0, nb_lo, nbz);
-                    lsum += mix_node<T>(c_k0, i + 1 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 1) : v1, nb_lo, nbz);
-                    lsum += mix_node<T>(c_k0, i + 2 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 2) : v2, nb_lo, nbz);
-                    lsum += mix_node<T>(c_k0, i + 3 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 3) : v3, nb_lo, nbz);
-                }
-                blk_chk += lsum;
-                BVG_T1(11, tqL2);
-                wave_sync();
-            }
-        }
-        BVG_T1(10, tqL);
-        if (rep) { blk_arcs += d; blk_nodes += 1; }
-
-        wave_sync();
-        // next row: lanes shift by k; reuse the prefetched offsets
-        r0 += k;
+        if (failed) break;
+        err |= pf & (a.fail_cap >> 31);                                      // (always 0: keeps the touches above alive)
+        // next super-row: reuse the prefetched offsets
+        r0 += K1;
         off_x = nxt_off; rec_end = nxt_end;
     }
 
@@ -701,6 +703,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         atomicAdd(&accs[1], (unsigned long long)blk_chk);
         atomicAdd(&accs[2], (unsigned long long)blk_nodes);
         if (err) atomicOr(&accs[3], (unsigned long long)err);
+        if (a.dbg & 64u) { atomicAdd(&a.acc[5], (unsigned long long)cnt_super); atomicAdd(&a.acc[6], (unsigned long long)cnt_sub); atomicAdd(&a.acc[7], (unsigned long long)cnt_nodes); }
 #ifdef BVG_PROF
         if (a.dbg & 64u) {
             for (int i = 0; i < 10; i++) atomicAdd(&a.acc[9 + i], (unsigned long long)cyc[i]);
@@ -717,7 +720,7 @@ size_t scan_static_lds() { return (size_t)kRing * 8 + 128 * 4; }
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
-    const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems) * 4;
+    const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
     hipLaunchKernelGGL(scan_kernel, dim3(nblocks), dim3(64), dyn, s, a);
 }
 
