@@ -163,6 +163,14 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             if (K1 > left) K1 = left;
         }
         if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF1u; break; }       // a single record larger than the window
+        // prefetch the next super-row's offsets now (their latency hides behind the header parse); the scratch area may still cut
+        // this super-row shorter, then they are fetched again below
+        const uint32_t K1win = K1;
+        uint64_t nxt_off = 0, nxt_end = 0;
+        {
+            const int64_t nx = r0 + K1 + lane;
+            if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
+        }
         uint32_t rel = (uint32_t)(off_x - stg_bit0);                          // bit cursor relative to the window
         const uint32_t pend = (uint32_t)(rec_end - stg_bit0);
         const uint32_t recrel = rel;
@@ -270,14 +278,40 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         const bool on1 = needed && lane < K1;
         uint64_t refmask = 0;
         for (uint32_t r = 1; r <= W && r < 64; r++) refmask |= ballot(parse && ref == r) >> r;
-        const bool stored = lane + W >= K1 || ((refmask >> lane) & 1ull);
-        const bool repn = on1 && x >= rep_lo && x < rep_hi;
-        // prefetch the next super-row's offsets (their latency hides behind this one's decode)
-        uint64_t nxt_off = 0, nxt_end = 0;
-        {
+        if (K1 != K1win) {
             const int64_t nx = r0 + K1 + lane;
+            nxt_off = 0; nxt_end = 0;
             if (nx < e) { nxt_off = a.offsets[nx]; nxt_end = a.offsets[nx + 1]; }
         }
+        // The last W nodes of the super-row can be referenced by the first W nodes of the next one: peek at those records' references
+        // (outdegree gamma, reference unary: BVG:654-660, 692-703) when they lie inside the staged window; otherwise, assume they are.
+        // Nodes of the next BLOCK do not count: that block decodes its halo itself.
+        {
+            uint32_t tgt = 64;                                                // lane of this super-row that my peeked node references
+            bool unknown = false;
+            const int64_t nx = r0 + K1 + lane;
+            if (lane < W && nx < e) {
+                unknown = true;
+                if (nxt_off >= stg_bit0 && nxt_end + 96 <= stg_bit0 + stg_bits) {
+                    uint32_t prel = (uint32_t)(nxt_off - stg_bit0);
+                    uint64_t pv;
+                    const uint32_t l = gamma64(win64<LIN>(stage, prel), pv);
+                    if (l != 0) {
+                        unknown = false;
+                        if (pv != 0) {
+                            const uint64_t w = win64<LIN>(stage, prel + l);
+                            const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                            if (lz > lane && lz <= W && lz - lane <= K1) tgt = K1 + lane - lz;     // reaches back into this super-row
+                            else if (lz >= 64) unknown = true;
+                        }
+                    }
+                }
+            }
+            if (ballot(unknown)) refmask |= K1 >= W ? (~0ull << (K1 - W)) : ~0ull;
+            for (uint32_t j = 0; j < W && j < 64; j++) { const uint32_t t = lane_get(tgt, j); if (t < 64) refmask |= 1ull << t; }
+        }
+        const bool stored = (refmask >> lane) & 1ull;
+        const bool repn = on1 && x >= rep_lo && x < rep_hi;
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
         uint32_t k0 = 0, k1 = 0;
         if (repn) {
@@ -720,7 +754,8 @@ size_t scan_static_lds() { return (size_t)kRing * 8 + 128 * 4; }
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
-    const size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
+    size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
+    if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
     hipLaunchKernelGGL(scan_kernel, dim3(nblocks), dim3(64), dyn, s, a);
 }
 
