@@ -241,6 +241,9 @@ void bvg_free(void* p);
  * of SURVEY.md), so the concatenation of K copies of the bit stream is a valid BVGraph with K*nodes
  * nodes in which copy j is the base graph shifted by j*nodes.  Built on the device. */
 int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out);
+/* The same with k <= 16 different base graphs (same device, same BV parameters): the cycle {bases[0], ..., bases[k-1]} repeated `cycles`
+ * times -- a synthetic workload whose tiles differ in seed and degree mix. */
+int bvg_mosaic(const bvg_graph* const* bases, int k, int64_t cycles, bvg_graph** out);
 
 /* ---- tuning knobs (optional) ---- */
 typedef struct bvg_tuning {

@@ -217,6 +217,35 @@ def test_wide_ids_beyond_32_bits(W, tools, oracle):
     assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]
 
 
+def test_mosaic_is_the_cycle_of_its_bases(W, tools, oracle):
+    """bvg_mosaic: the streams of several DIFFERENT graphs back to back, the cycle repeated (the bench's workload): equals the host
+    twin tools.mosaic_host bit for bit, decodes to the bases' lists shifted by their first node, checksums add up."""
+    sts = [tools.synth_store(n, seed=sd, synth=sy, threads=2) for n, sd, sy in
+           ((3000, 1, tools.eu_like(mean_deg=40.0)), (1777, 2, tools.web_like()), (4097, 3, tools.eu_like(mean_deg=90.0, p_copy=0.8)))]
+    gs = [W.BVGraph.from_memory(st.params, st.graph, st.offsets) for st in sts]
+    cycles = 3
+    m = W.mosaic(gs, cycles)
+    host = tools.mosaic_host(sts, cycles)
+    assert m.num_nodes() == host.params.nodes and np.array_equal(m.offsets(), host.offsets)
+    deg, succ = m.decode_range(0, m.num_nodes())
+    og = oracle.Graph.from_memory(oracle.Params(**host.params.as_dict()), host.graph.tobytes(), host.offsets)
+    odeg, osucc = og.decode_range(0, host.params.nodes)
+    assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc)
+    chk = arcs = 0; first = 0
+    for c in range(cycles):
+        for st in sts:
+            o = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets).scan(0, st.params.nodes, node_base=first)
+            r = m.scan(first, first + st.params.nodes)
+            assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"]), (c, first)
+            chk = (chk + o["chk"]) % (1 << 64); arcs += o["arcs"]; first += st.params.nodes
+    r = m.scan()
+    assert (r["arcs"], r["chk"]) == (arcs, chk)
+    with pytest.raises(W.IllegalArgumentException):                    # bases must share the BV parameters
+        st2 = tools.synth_store(500, seed=9, params=W.default_params(window_size=3), threads=1)
+        W.mosaic([gs[0], W.BVGraph.from_memory(st2.params, st2.graph, st2.offsets)], 1)
+    m.close()
+
+
 def test_full_size_properties_on_a_tiled_graph(W, tools, oracle):
     """Size-independent properties at bench scale (a ~0.5 GiB tiled stream, hundreds of millions of arcs):
     (1) the checksum of K tiles equals the sum of K base scans with shifted node bases (translation

@@ -10,4 +10,4 @@ from .bvgraph import (BVGraph, NodeIterator, LazyLongIterator, BVGraphError, Ill
                       IllegalStateException, UnsupportedOperationException, IOException, EOFException, DeviceError,
                       NoSuchElementException, parse_properties, decode_offsets, arc_mix, build, lib, library_path,
                       BitStreamArcLabelledImmutableGraph, LabelledArcIterator, parse_label_spec, LABEL_GAMMA_INT, LABEL_FIXED_INT, LABEL_FIXED_INT_LIST, LABEL_FIXED_LONG_LIST,
-                      scan_multi, BALANCE_NODES, BALANCE_BITS, BALANCE_ARCS, store)
+                      scan_multi, mosaic, BALANCE_NODES, BALANCE_BITS, BALANCE_ARCS, store)

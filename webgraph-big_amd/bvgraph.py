@@ -138,6 +138,7 @@ def lib():
         L.bvg_labels_decode_range_lists.argtypes = [vp, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_labels_decode_range_lists64.argtypes = [vp, i64, i64, vp, vp, vp, u64, C.POINTER(u64)]
         L.bvg_tile.argtypes = [vp, i64, pp]
+        L.bvg_mosaic.argtypes = [vp, C.c_int, i64, pp]
         L.bvg_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
         L.bvg_arc_mix.argtypes = [u64, u64]; L.bvg_arc_mix.restype = u64
@@ -697,6 +698,15 @@ class BVGraph:
 
 
 BALANCE_NODES, BALANCE_BITS, BALANCE_ARCS = 0, 1, 2
+
+
+def mosaic(graphs, cycles):
+    """Synthetic workload helper (bvg_mosaic): the cycle of the given base graphs, back to back, repeated `cycles` times."""
+    k = len(graphs)
+    hs = (C.c_void_p * k)(*[g._h for g in graphs])
+    h = C.c_void_p()
+    _check(lib().bvg_mosaic(hs, k, cycles, C.byref(h)), "mosaic")
+    return BVGraph(h)
 
 
 def scan_multi(graphs, balance=BALANCE_ARCS):

@@ -610,11 +610,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
                 // queue) + static arrays.  Resident wavefronts per CU step down with it; take the largest even count whose pool
                 // still holds a row's worth of lists (leaves take no pool: about half the row kernel's need).
-                const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 512);   // a super-row: the records that fit it, up to 64
-                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 640;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
+                const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 384);   // a super-row: the records that fit it, up to 64 (profiles/r03_ab_cfg.txt)
+                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 512;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
                 const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64 + (uint64_t)stagew * 4 + scrw * 4;
                 auto foot = [&](uint64_t pe) { return (pe * 4 + fixed + 127) & ~127ull; };
-                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 14.0;   // window lists + a sub-row's stored lists and parked residuals
+                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 18.0;   // window lists + a sub-row's stored lists and parked residuals
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
                 for (uint64_t w : {16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
@@ -1606,33 +1606,52 @@ static int bvg_build_index_impl(bvg_graph* g, int64_t from, int64_t to, uint64_t
     return 0;
 }
 
-static int bvg_tile_impl(const bvg_graph* base, int64_t copies, bvg_graph** out) {
-    if (!base || !out || copies < 1) return BVG_E_ARG;
-    Shared* b = base->sh;
-    HIPCHK(hipSetDevice(b->device));
-    const int64_t n = b->p.nodes;
-    if (n <= 0 || b->total_bits == 0) return BVG_E_ARG;
-    if (copies > INT64_MAX / n) return BVG_E_ARG;
-    const uint64_t total_bits = b->total_bits * (uint64_t)copies;
+static int bvg_mosaic_impl(const bvg_graph* const* bases, int k, int64_t cycles, bvg_graph** out) {
+    if (!bases || !out || k < 1 || k > kMosaicMax || cycles < 1) return BVG_E_ARG;
+    for (int i = 0; i < k; i++) if (!bases[i]) return BVG_E_ARG;
+    Shared* b0 = bases[0]->sh;
+    HIPCHK(hipSetDevice(b0->device));
+    MosaicSrc m{}; m.k = k;
+    int64_t arcs = 0;
+    for (int i = 0; i < k; i++) {
+        Shared* b = bases[i]->sh;
+        const bvg_params &p = b->p, &q = b0->p;
+        if (b->device != b0->device || b->p.nodes <= 0 || b->total_bits == 0) return BVG_E_ARG;
+        if (p.window_size != q.window_size || p.min_interval_length != q.min_interval_length || p.zeta_k != q.zeta_k || p.outdegree_coding != q.outdegree_coding ||
+            p.block_coding != q.block_coding || p.residual_coding != q.residual_coding || p.reference_coding != q.reference_coding || p.block_count_coding != q.block_count_coding) return BVG_E_ARG;
+        m.graph[i] = b->d_graph; m.offs[i] = b->offs; m.bits[i] = b->total_bits;
+        m.bit_prefix[i + 1] = m.bit_prefix[i] + b->total_bits; m.node_prefix[i + 1] = m.node_prefix[i] + p.nodes;
+        arcs = (arcs < 0 || p.arcs < 0) ? -1 : arcs + p.arcs;
+    }
+    m.cycle_bits = m.bit_prefix[k]; m.cycle_nodes = m.node_prefix[k];
+    if (cycles > INT64_MAX / m.cycle_nodes) return BVG_E_ARG;
+    const uint64_t total_bits = m.cycle_bits * (uint64_t)cycles;
     const uint64_t nbytes = (total_bits + 7) / 8;
     const uint64_t padded = ((nbytes + 15) & ~15ull) + kPad;
+    const int64_t n = m.cycle_nodes * cycles;
     uint8_t* d_graph = nullptr; uint32_t* d_lo = nullptr; uint64_t* d_hi = nullptr;
-    const size_t n1 = (size_t)(n * copies) + 1;
+    const size_t n1 = (size_t)n + 1;
+    DevBuf flag;
+    if (flag.alloc(sizeof(unsigned)) || hipMemset(flag.p, 0, sizeof(unsigned)) != hipSuccess) return BVG_E_NOMEM;
     HIPCHK(hipMalloc(&d_graph, padded));
     if (hipMalloc(&d_lo, n1 * sizeof(uint32_t)) != hipSuccess || hipMalloc(&d_hi, ((n1 >> kOffShift) + 2) * sizeof(uint64_t)) != hipSuccess) {
         (void)hipFree(d_graph); if (d_lo) (void)hipFree(d_lo); return BVG_E_NOMEM;
     }
-    launch_tile_graph(b->d_graph, b->total_bits, d_graph, padded, copies, base->stream);
-    launch_tile_offsets(b->offs, n, b->total_bits, d_lo, d_hi, copies, base->stream);   // (distances fit 32 bits wherever the base's do)
-    HIPCHK(hipStreamSynchronize(base->stream));
-    bvg_params p = b->p; p.nodes = n * copies; if (p.arcs >= 0) p.arcs *= copies;
+    hipStream_t st = bases[0]->stream;
+    launch_mosaic_graph(m, d_graph, padded, cycles, st);
+    launch_mosaic_offsets(m, cycles, d_lo, d_hi, (unsigned*)flag.p, st);
+    unsigned over = 0;
+    if (hipMemcpyAsync(&over, flag.p, sizeof over, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) over = 2;
+    if (over) { (void)hipFree(d_graph); (void)hipFree(d_lo); (void)hipFree(d_hi); return over == 2 ? BVG_E_HIP : BVG_E_UNSUPPORTED; }   // a group of 2^kOffShift records spans 2^32 bits: not packable
+    bvg_params p = b0->p; p.nodes = n; p.arcs = arcs < 0 ? -1 : arcs * cycles;
     const PackedOffsets pk{d_lo, d_hi};
-    int r = open_common(&p, nullptr, d_graph, nbytes, nullptr, nullptr, b->device, out, &pk);
+    int r = open_common(&p, nullptr, d_graph, nbytes, nullptr, nullptr, b0->device, out, &pk);
     if (r) { (void)hipFree(d_graph); return r; }                      // (open_common owns the index from the start)
     (*out)->sh->own_graph = true;
-    (*out)->tun = base->tun;
+    (*out)->tun = bases[0]->tun;
     return 0;
 }
+static int bvg_tile_impl(const bvg_graph* base, int64_t copies, bvg_graph** out) { return bvg_mosaic_impl(&base, 1, copies, out); }
 
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out) { return guarded([&] { return bvg_scan_impl(g, from, to, out); }); }
 // Shard bounds of a k-way split of the node range (ImmutableGraph.splitNodeIterators, IG:405-436): BVG_BALANCE_NODES is the
@@ -1644,6 +1663,7 @@ int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_re
 int bvg_build_index(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, uint64_t* bytes) { return guarded([&] { return bvg_build_index_impl(g, from, to, entries, bytes); }); }
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) { return guarded([&] { return bvg_successors_batch_impl(g, nodes, count, outdeg, succ, succ_cap, n_succ); }); }
 int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) { return guarded([&] { return bvg_tile_impl(base, copies, out); }); }
+int bvg_mosaic(const bvg_graph* const* bases, int k, int64_t cycles, bvg_graph** out) { return guarded([&] { return bvg_mosaic_impl(bases, k, cycles, out); }); }
 int bvg_split_by_arcs(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_arcs_impl(g, k, bounds); }); }
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds) { return guarded([&] { return bvg_split_by_bits_impl(g, k, bounds); }); }
 

@@ -159,9 +159,16 @@ void launch_derive_offsets(const uint8_t* graph, uint64_t padded_bytes, uint64_t
 int encode_store_dev(const bvg_params& p, const uint64_t* d_adj_off, const int64_t* d_adj, int64_t n, int64_t chunk_nodes, hipStream_t s,
                      uint8_t** d_graph_out, uint64_t* graph_bytes, uint64_t** d_offsets_out);
 
-// synthetic tiling (bvg_tile)
-void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s);
-void launch_tile_offsets(Offsets src, int64_t n, uint64_t src_bits, uint32_t* dst_lo, uint64_t* dst_hi, int64_t copies, hipStream_t s);   // packed output
+// synthetic workloads (bvg_tile / bvg_mosaic): the cycle {base 0, ..., base k-1} repeated
+constexpr int kMosaicMax = 16;
+struct MosaicSrc {
+    int k;
+    const uint8_t* graph[kMosaicMax]; Offsets offs[kMosaicMax];
+    uint64_t bits[kMosaicMax], bit_prefix[kMosaicMax + 1]; int64_t node_prefix[kMosaicMax + 1];
+    uint64_t cycle_bits; int64_t cycle_nodes;
+};
+void launch_mosaic_graph(const MosaicSrc& m, uint8_t* dst, uint64_t dst_bytes, int64_t cycles, hipStream_t s);
+void launch_mosaic_offsets(const MosaicSrc& m, int64_t cycles, uint32_t* dst_lo, uint64_t* dst_hi, unsigned* overflow, hipStream_t s);   // packed output
 
 // transposition feed (bvg_transpose.hip): stable radix sort of (target, source) pairs + in-degree prefix
 size_t transpose_temp_bytes(uint64_t arcs, int64_t n);

@@ -486,41 +486,47 @@ __device__ __forceinline__ uint64_t load_bits64(const uint8_t* src, uint64_t bit
     if (sh) w |= (uint64_t)p[8] >> (8u - sh);
     return w;
 }
-__global__ void tile_graph_kernel(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_words, uint64_t total_bits) {
+// A MOSAIC: the streams of up to kMosaicMax base graphs concatenated, the whole cycle repeated `cycles` times (BV records are
+// translation invariant: a record decodes to the same lists shifted by the node id it is given).  One base = the old bvg_tile.
+__global__ void mosaic_graph_kernel(MosaicSrc m, uint8_t* dst, uint64_t dst_words, uint64_t total_bits) {
     // grid-stride: a launch may not exceed 2^32 threads (a 47 GB stream has 5.9e9 words)
     for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < dst_words; w += (uint64_t)gridDim.x * blockDim.x) {
-    uint64_t P = w * 64, val = 0;
-    if (P < total_bits) {
-        uint64_t off = P % src_bits, rem = src_bits - off;
-        if (rem >= 64) val = load_bits64(src, off);
-        else {
-            val = load_bits64(src, off) & ~(~0ull >> rem);                   // top `rem` bits
-            unsigned got = (unsigned)rem;
-            while (got < 64) {                                               // src_bits may be < 64
-                uint64_t piece = load_bits64(src, 0);
-                uint64_t take = src_bits < 64u - got ? src_bits : 64u - got;
+        const uint64_t P = w * 64;
+        uint64_t val = 0;
+        if (P < total_bits) {
+            uint64_t off = P % m.cycle_bits;
+            int k = 0;
+            while (k + 1 < m.k && off >= m.bit_prefix[k + 1]) k++;
+            off -= m.bit_prefix[k];
+            unsigned got = 0;
+            while (got < 64) {                                                // a word may straddle several (short) sources
+                const uint64_t rem = m.bits[k] - off;
+                uint64_t piece = load_bits64(m.graph[k], off);
+                const uint64_t take = rem < 64u - got ? rem : 64u - got;
                 piece &= take >= 64 ? ~0ull : ~(~0ull >> take);
                 val |= piece >> got;
                 got += (unsigned)take;
+                off += take;
+                if (off >= m.bits[k]) { off = 0; k = k + 1 < m.k ? k + 1 : 0; }
             }
+            if (total_bits - P < 64) val &= ~(~0ull >> (total_bits - P));
         }
-        if (total_bits - P < 64) val &= ~(~0ull >> (total_bits - P));
-    }
-    reinterpret_cast<uint64_t*>(dst)[w] = __builtin_bswap64(val);
+        reinterpret_cast<uint64_t*>(dst)[w] = __builtin_bswap64(val);
     }
 }
-__device__ __forceinline__ uint64_t tiled_offset(const Offsets& src, int64_t n, uint64_t src_bits, int64_t copies, int64_t i) {
-    if (i >= n * copies) return (uint64_t)copies * src_bits;
-    const int64_t c = i / n, r = i - c * n;
-    return (uint64_t)c * src_bits + src[r];
+__device__ __forceinline__ uint64_t mosaic_offset(const MosaicSrc& m, int64_t tot, int64_t i) {
+    if (i >= tot) return (uint64_t)(tot / m.cycle_nodes) * m.cycle_bits;
+    const int64_t c = i / m.cycle_nodes; int64_t r = i - c * m.cycle_nodes;
+    int k = 0;
+    while (k + 1 < m.k && r >= m.node_prefix[k + 1]) k++;
+    return (uint64_t)c * m.cycle_bits + m.bit_prefix[k] + m.offs[k][r - m.node_prefix[k]];
 }
-// offsets of `copies` concatenated copies, written in packed form straight away (a tile never spans 2^32 bits per 2^kOffShift nodes
-// unless its source does)
-__global__ void tile_offsets_kernel(Offsets src, int64_t n, uint64_t src_bits, uint32_t* dst_lo, uint64_t* dst_hi, int64_t copies) {
-    const int64_t tot = n * copies;
+// offsets of the mosaic, written in packed form straight away; *overflow != 0 if 2^kOffShift consecutive records span 2^32 bits or more
+__global__ void mosaic_offsets_kernel(MosaicSrc m, int64_t tot, uint32_t* dst_lo, uint64_t* dst_hi, unsigned* overflow) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= tot; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t v = tiled_offset(src, n, src_bits, copies, i);
-        const uint64_t b = tiled_offset(src, n, src_bits, copies, i & ~(((int64_t)1 << kOffShift) - 1));
+        const uint64_t v = mosaic_offset(m, tot, i);
+        const uint64_t b = mosaic_offset(m, tot, i & ~(((int64_t)1 << kOffShift) - 1));
+        if (v - b > 0xFFFFFFFFull) atomicOr(overflow, 1u);
         dst_lo[i] = (uint32_t)(v - b);
         if ((i & (((int64_t)1 << kOffShift) - 1)) == 0) dst_hi[i >> kOffShift] = v;
     }
@@ -634,13 +640,13 @@ void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets
     hipLaunchKernelGGL(plan_maxd_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, graph, limit_byte, offsets, first, halo, nblk, coding, window, maxd);
 }
 
-void launch_tile_graph(const uint8_t* src, uint64_t src_bits, uint8_t* dst, uint64_t dst_bytes, int64_t copies, hipStream_t s) {
-    uint64_t words = dst_bytes / 8;
-    hipLaunchKernelGGL(tile_graph_kernel, dim3((unsigned)std::min<uint64_t>((words + 255) / 256, 1u << 22)), dim3(256), 0, s, src, src_bits, dst, words, src_bits * (uint64_t)copies);
+void launch_mosaic_graph(const MosaicSrc& m, uint8_t* dst, uint64_t dst_bytes, int64_t cycles, hipStream_t s) {
+    const uint64_t words = dst_bytes / 8;
+    hipLaunchKernelGGL(mosaic_graph_kernel, dim3((unsigned)std::min<uint64_t>((words + 255) / 256, 1u << 22)), dim3(256), 0, s, m, dst, words, m.cycle_bits * (uint64_t)cycles);
 }
-void launch_tile_offsets(Offsets src, int64_t n, uint64_t src_bits, uint32_t* dst_lo, uint64_t* dst_hi, int64_t copies, hipStream_t s) {
-    int64_t tot = n * copies + 1;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3((unsigned)std::min<int64_t>((tot + 255) / 256, 1 << 22)), dim3(256), 0, s, src, n, src_bits, dst_lo, dst_hi, copies);
+void launch_mosaic_offsets(const MosaicSrc& m, int64_t cycles, uint32_t* dst_lo, uint64_t* dst_hi, unsigned* overflow, hipStream_t s) {
+    const int64_t tot = m.cycle_nodes * cycles;
+    hipLaunchKernelGGL(mosaic_offsets_kernel, dim3((unsigned)std::min<int64_t>((tot + 256) / 256, 1 << 22)), dim3(256), 0, s, m, tot, dst_lo, dst_hi, overflow);
 }
 void launch_pack_offsets(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow, hipStream_t s) {
     if (count <= 0) return;

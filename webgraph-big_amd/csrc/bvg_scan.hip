@@ -37,6 +37,7 @@ using namespace rows;
 #ifndef BVG_SCAN_CHUNK
 #define BVG_SCAN_CHUNK 8
 #endif
+constexpr uint32_t kNoList = 0xFFFFu;
 constexpr uint32_t kQueueMin = 48;             // run descriptors the scratch area always keeps room for
 constexpr uint32_t kChunk = BVG_SCAN_CHUNK;    // leaf elements per lane and pass (a kept copy block of a web graph is ~9 elements long)
 
@@ -44,8 +45,8 @@ typedef uint32_t T;
 
 __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
-    __shared__ uint32_t nd_base[kRing];
-    __shared__ uint32_t nd_d[kRing];
+    __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
+    __shared__ uint16_t nd_d[kRing];              // outdegree, clamped (a list longer than the pool fails the block before anything copies from it)
     __shared__ uint32_t rtmap[128];               // task maps: residual segments -> lanes (two per lane), extras / positions / chunks -> lanes
 
     const unsigned lane = threadIdx.x;
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     auto compact = [&](int64_t upto) {
         uint32_t my_d = 0, my_base = 0; const int64_t y = upto - (int64_t)W + (int64_t)lane;
         const bool livelane = lane < W && y >= hs;
-        if (livelane) { my_base = nd_base[(uint32_t)y & RM]; my_d = my_base == kInf ? 0u : nd_d[(uint32_t)y & RM]; }
+        if (livelane) { my_base = nd_base[(uint32_t)y & RM]; my_d = my_base == kNoList ? 0u : nd_d[(uint32_t)y & RM]; }
         const uint32_t nincl = wave_incl_scan32(my_d);
         const uint32_t nbase = nincl - my_d;
         for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             if (src != dst && len)
                 for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
         }
-        if (livelane && my_base != kInf) nd_base[(uint32_t)y & RM] = nbase;
+        if (livelane && my_base != kNoList) nd_base[(uint32_t)y & RM] = (uint16_t)nbase;
         pool_used = lane_get(nincl, 63);
         wave_sync();
     };
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             bad |= l == 0 || v > 0x7FFFFFFFull; rel += l; d = bad ? 0u : (uint32_t)v;
         }
         const uint32_t dclamp = d > CAP ? CAP + 1 : d;
-        if (needed && lane < K1) nd_d[(uint32_t)x & RM] = d;
+        if (needed && lane < K1) nd_d[(uint32_t)x & RM] = (uint16_t)(d < 0xFFFFu ? d : 0xFFFFu);
         wave_sync();
         BVG_T1(6, tq5);
         const uint32_t tq7 = BVG_T0();
@@ -261,6 +262,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     rel += l1 + l2;
                     const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
                     const int64_t len = (int64_t)v2 + minint;
+                    if (len > 0xFFFFFF) bad = true;                           // (a run descriptor holds 24 bits of length: leave such a list to the row kernel)
                     prev = leftv + len;
                     extra -= len;
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
@@ -361,7 +363,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const uint32_t base = pool_used + (sincl - size);
             const uint32_t rtb = CAP - (rincl > CAP ? CAP : rincl);
             const uint32_t qs = qincl - nq, Q = lane_get(qincl, se - 1);
-            if (act) nd_base[(uint32_t)x & RM] = stored ? base : kInf;        // (a leaf has no list: nothing to compact, nothing to copy from)
+            if (act) nd_base[(uint32_t)x & RM] = (uint16_t)(stored ? base : kNoList);        // (a leaf has no list: nothing to compact, nothing to copy from)
             pool_used += lane_get(sincl, se - 1);
             BVG_T1(8, tq8b);
             const uint32_t tq9 = BVG_T0();
@@ -750,7 +752,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
 }  // namespace
 
 // what the kernel needs of LDS besides the pool and the scratch area (static arrays)
-size_t scan_static_lds() { return (size_t)kRing * 8 + 128 * 4; }
+size_t scan_static_lds() { return (size_t)kRing * 4 + 128 * 4; }
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;

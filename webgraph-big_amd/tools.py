@@ -171,6 +171,37 @@ def tile_host(st, copies):
     return Stored(p, out[:(total + 7) // 8], offs, stats)
 
 
+def mosaic_host(sts, cycles):
+    """Host twin of bvg_mosaic: the cycle of the stored graphs `sts`, back to back, repeated `cycles` times, as one Stored."""
+    def put(out, o, src, nbits):
+        nb = (nbits + 7) // 8
+        piece = src[:nb].copy()
+        if nbits & 7:
+            piece[-1] &= np.uint8((0xFF << (8 - (nbits & 7))) & 0xFF)    # padding bits of the last byte must stay clear
+        b0 = o >> 3; sh = o & 7
+        if sh == 0:
+            out[b0:b0 + nb] |= piece
+        else:
+            out[b0:b0 + nb] |= piece >> np.uint8(sh)
+            out[b0 + 1:b0 + 1 + nb] |= (piece << np.uint8(8 - sh)) & np.uint8(0xFF)
+    bits = [int(st.offsets[-1]) for st in sts]
+    cyc_bits = sum(bits); total = cyc_bits * cycles
+    out = np.zeros((total + 7) // 8 + 2, dtype=np.uint8)
+    ns = [int(st.params.nodes) for st in sts]
+    offs = np.empty(sum(ns) * cycles + 1, dtype=np.uint64)
+    o = 0; i = 0
+    for c in range(cycles):
+        for st, nb, n in zip(sts, bits, ns):
+            put(out, o, np.ascontiguousarray(st.graph, dtype=np.uint8), nb)
+            offs[i:i + n] = st.offsets[:n] + np.uint64(o)
+            o += nb; i += n
+    offs[-1] = total
+    arcs = sum(int(st.stats["arcs"]) for st in sts) * cycles
+    p = sts[0].params.clone(nodes=sum(ns) * cycles, arcs=arcs)
+    stats = dict(sts[0].stats); stats["arcs"] = arcs
+    return Stored(p, out[:(total + 7) // 8], offs, stats)
+
+
 def synth_adjacency(n, seed=0, synth=None, chunk_nodes=1 << 16):
     sp = synth or web_like()
     po = C.c_void_p(); pa = C.c_void_p()
