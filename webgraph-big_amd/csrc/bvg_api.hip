@@ -677,7 +677,15 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (ngiant) {
                 // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
                 gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : 1024u);
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : 8192u);
+                {   // every giant block of the scan in one launch where memory allows (batches run one after the other on their side
+                    // stream, and the first one shares the chip with tier 0 for the whole scan: profiles/r03_ktrace_d14.txt), at most 1/8 of what is free
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / 8;
+                        gbatch = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(gbatch, room / std::max<uint64_t>(per, 1)), std::min<uint32_t>(ngiant, 256u));
+                    }
+                }
                 const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
                 if (bytes > g->giant_ws_bytes) {
                     if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
@@ -691,6 +699,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             off += pd.count[0];
             size_t offc[12]; { size_t o = 0; for (int c = 0; c < 12; c++) { offc[c] = o; o += pd.count[c]; } }
             const bool tier0_first = knob("BVG_ORDER") && atoi(knob("BVG_ORDER")) == 1;
+            const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
+            auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
@@ -701,24 +711,24 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                         const uint32_t nb = std::min<uint32_t>(gbatch, pd.count[c] - o2);
                         if (c == 5) launch_giant_decode(ag, nb, wide, materialise, g->side[0]);
                         else launch_decode(ag, nb, wide, materialise, true, g->side[0]);
-                        launches++;
+                        launches++; alone(g->side[0]);
                     }
             }
             for (int c = 4; c >= 1; c--) {                                     // LDS size classes, largest first
                 if (!pd.count[c]) continue;
                 DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_rows_any(ac, pd.count[c], g->side[knob("BVG_SIDE6") ? c : 1 + (c & 1)], true);   // two side streams for the classes: with tier 0 and the giants that is four queues, what the runtime maps to hardware queues one to one
+                launch_rows_any(ac, pd.count[c], g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c], true); alone(g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c]);   // a side stream per class: a short class queued behind a long one ran after everything else had finished
                 launches++;
             }
             for (int c = 4; c >= 1; c--) {                                     // the same classes of the lean scan kernel
                 if (!pd.count[7 + c]) continue;
                 DecodeArgs ac = af; ac.work_list = pd.d_lists + offc[7 + c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_scan_decode(ac, pd.count[7 + c], g->side[1 + (c & 1)]);
+                launch_scan_decode(ac, pd.count[7 + c], g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c]); alone(g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c]);
                 launches++;
             }
-            if (pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], g->stream); launches++; }
+            if (pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));

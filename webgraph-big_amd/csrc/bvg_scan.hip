@@ -128,16 +128,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
         const uint32_t left = (uint32_t)(e - r0 > 64 ? 64 : e - r0);
         if (pool_used > 0) compact(r0);
-        // Touch what the wavefront will wait for later, so that it comes from L2 instead of HBM: the 2 KiB of stream behind this
-        // super-row's last record (the next super-row's window) and the skip entries of this super-row's long residual lists.  The
-        // values are never used (the mask below is zero); the loads only have to be issued.
-        uint32_t pf = 0;
-        if (a.dbg != 0xFFFFFFFFu) {
-            const uint64_t nb0 = ((lane_get64(rec_end, left - 1) >> 3) & ~127ull) + (uint64_t)lane * 128u;
-            if (lane < 18 && nb0 + 4 <= a.padded_bytes) pf = *reinterpret_cast<const uint32_t*>(a.graph + nb0);
-            if (lane >= 32 && lane < 36) { const uint32_t ix = sk_run + (lane - 32u) * 64u; if (ix < sk_n) pf ^= a.skip_bit[sk_base + ix]; }
-            if (lane >= 40 && lane < 48) { const uint32_t ix = sk_run + (lane - 40u) * 32u; if (ix < sk_n) pf ^= reinterpret_cast<const T*>(a.skip_val)[sk_base + ix]; }
-        }
         {   // (re)stage the window when this super-row's records are not covered by it
             const uint64_t row_lo = lane_get64(off_x, 0);
             const uint64_t row_hi = lane_get64(rec_end, left - 1);
@@ -271,6 +261,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             }
             nres = (uint32_t)extra;
         }
+          // the touches have landed long ago; their registers are free again
         if (ballot(bad && lane < K1)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
         BVG_T1(7, tq7);
         const uint32_t tq8 = BVG_T0();
@@ -718,7 +709,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             if (sa < K1) compact(r0 + (int64_t)sa);                            // the next sub-row starts from the stored lists of the W nodes before it
         }
         if (failed) break;
-        err |= pf & (a.fail_cap >> 31);                                      // (always 0: keeps the touches above alive)
         // next super-row: reuse the prefetched offsets
         r0 += K1;
         off_x = nxt_off; rec_end = nxt_end;
