@@ -97,7 +97,8 @@ def main():
     import numpy as np
     import torch
     import webgraph_big_amd as W
-    from webgraph_big_amd import tools as T, shard as S
+    import tooling as T
+    from webgraph_big_amd import shard as S
 
     if args.one_device:
         local_rank = 0
@@ -328,7 +329,7 @@ def cpu_baseline(sts, bases_gpu, basename, threads, gib):
     a prefix of its nodes), node ranges split as ImmutableGraph.splitNodeIterators does."""
     import numpy as np
     from oracle import bvg_oracle as O
-    from webgraph_big_amd import tools as T
+    import tooling as T
     if sts:
         k = max(1, int(round(gib * (1 << 30) / max(sum(len(st.graph) for st in sts), 1))))
         ts = T.mosaic_host(sts, k)

@@ -195,7 +195,8 @@ int bvg_symmetrize_dev(bvg_graph* g, void* d_soffsets, void* d_ssucc, uint64_t s
  * gamma-coded bit lengths of those runs after a leading gamma(0) (store(), :655-680).  The node iterator reads `outdegree`
  * labels per node (:565-582).  Built for the scalar label classes: GammaCodedIntLabel (GammaCodedIntLabel.java:60-64) and
  * FixedWidthIntLabel (FixedWidthIntLabel.java:70-73), and for FixedWidthIntListLabel (FixedWidthIntListLabel.java:73-78:
- * gamma length + elements of `width` bits per arc); FixedWidthLongListLabel and user classes return BVG_E_UNSUPPORTED. */
+ * gamma length + elements of `width` bits per arc) and FixedWidthLongListLabel (elements of up to 64 bits, below); user label
+ * classes return BVG_E_UNSUPPORTED. */
 enum { BVG_LABEL_GAMMA_INT = 1, BVG_LABEL_FIXED_INT = 2, BVG_LABEL_FIXED_INT_LIST = 3, BVG_LABEL_FIXED_LONG_LIST = 4 };
 typedef struct bvg_labels bvg_labels;
 /* Label.toSpec() text, e.g. "it.unimi.dsi.big.webgraph.labelling.FixedWidthIntLabel(FOO,10)" -> kind, width. */

@@ -32,6 +32,8 @@ class Bits(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("BVG_ORACLE_LIB"):                     # an alternative build of the same source (oracle/Makefile `asan`: tests/test_sanitizers.py)
+        return os.environ["BVG_ORACLE_LIB"]
     so = os.path.join(_HERE, "libbvg_oracle.so")
     src = [os.path.join(_HERE, f) for f in ("bvg_oracle.c", "bvg_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):

@@ -4,7 +4,7 @@ import ctypes as C, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 shape = sys.argv[1] if len(sys.argv) > 1 else 'eu'
 n = 1 << 21
 synth = T.eu_like() if shape == 'eu' else T.web_like()

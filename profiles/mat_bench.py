@@ -3,7 +3,7 @@ import ctypes as C, sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 shape = sys.argv[1] if len(sys.argv) > 1 else 'eu'
 st = T.synth_store(1 << 21, seed=0, synth=T.eu_like() if shape == 'eu' else T.web_like(), threads=32)
 base = W.BVGraph.from_memory(st.params, st.graph, st.offsets)

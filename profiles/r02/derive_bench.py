@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 st = T.synth_store(1 << 21, seed=0, synth=T.eu_like(), threads=16)
 big = T.tile_host(st, max(1, int(gib * (1 << 30) / len(st.graph))))

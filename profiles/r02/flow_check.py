@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ["BVG_FLOW"] = "1"
 import numpy as np
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 from oracle import bvg_oracle as O
 ok = True
 for name, n, sp, kw in (("eu", 30000, T.eu_like(), {}), ("eu15", 30000, T.eu_like(mean_deg=127.5), {}), ("web", 50000, T.web_like(), {}),

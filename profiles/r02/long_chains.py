@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 for mr in (3, 10, 100, -1):
     st = T.synth_store(1 << 21, seed=3, params=W.default_params(window_size=7, max_ref_count=mr), synth=T.eu_like(), threads=16)
     g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--batch-nodes", type=int, default=1 << 20)
     args = ap.parse_args()
     import webgraph_big_amd as W
-    from webgraph_big_amd import tools as T
+    import tooling as T
     from oracle import bvg_oracle as O
     import bench as B
     kind, skw, pkw, _, wl = B.SHAPES[args.shape]

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 for name, sp, n in (("eu", T.eu_like(), 1 << 21), ("web", T.web_like(), 1 << 22)):
     off, adj = T.synth_adjacency(n, seed=0, synth=sp, chunk_nodes=1 << 16)
     p = W.default_params()

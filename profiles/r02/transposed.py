@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 
 def scans(g, what, k=3):
     for it in range(k):

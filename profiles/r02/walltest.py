@@ -1,7 +1,7 @@
 import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 st = T.synth_store(1 << 21, seed=0, params=W.default_params(), synth=T.eu_like(mean_deg=127.5), threads=16)
 base = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
 g = base.tile(36)

@@ -2,7 +2,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 for w, mr in ((7, 3), (64, 3), (70, 3), (70, 1000)):
     st = T.synth_store(1 << 20, seed=3, params=W.default_params(window_size=w, max_ref_count=mr), synth=T.eu_like(), threads=16)
     g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)

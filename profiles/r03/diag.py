@@ -5,7 +5,7 @@ os.environ.setdefault("BVG_TEST_KNOBS", "1"); os.environ.setdefault("BVG_EMIT", 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 from oracle import bvg_oracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40000

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 from oracle import bvg_oracle as O
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300

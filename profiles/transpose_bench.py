@@ -3,7 +3,7 @@ import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 import webgraph_big_amd as W
-from webgraph_big_amd import tools as T
+import tooling as T
 for shape, synth in (("eu", T.eu_like()), ("web", T.web_like())):
     st = T.synth_store(1 << 21, seed=0, params=W.default_params(), synth=synth, threads=32)
     base = W.BVGraph.from_memory(st.params, st.graph, st.offsets)

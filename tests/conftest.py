@@ -57,7 +57,7 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def tools():
-    from webgraph_big_amd import tools as T
+    import tooling as T
     T.lib()
     return T
 

@@ -45,6 +45,21 @@ def test_cnr2000_outdegrees_and_random_access(cnr_gpu, cnr_golden):
         assert it.next_long() == -1          # -1 forever after the end (WebGraphTestCase.java:125)
 
 
+def test_cnr2000_random_access_of_every_node(cnr_gpu, cnr_csr):
+    """BVGraphTest.java:112-121 (testLarge) checks successors(x) of EVERY node of the fixture, in random order: here the whole node
+    set as one frontier of bvg_successors_batch (each request decoded with its own reference chain, BVG:1084), in a random
+    permutation, against the reference's golden."""
+    gdeg, gsucc = cnr_csr
+    n = cnr_gpu.num_nodes()
+    cum = np.concatenate([[0], np.cumsum(gdeg, dtype=np.int64)])
+    perm = np.random.default_rng(5).permutation(n).astype(np.int64)
+    for part in np.array_split(perm, 4):
+        d, s = cnr_gpu.successors_batch(part)
+        assert np.array_equal(d, gdeg[part])
+        exp = np.concatenate([gsucc[cum[x]:cum[x + 1]] for x in part])
+        assert np.array_equal(s, exp)
+
+
 @pytest.mark.parametrize("frm,to", [(0, 1), (5, 77), (1000, 5000), (325000, 325557), (123456, 123457), (64, 64)])
 def test_cnr2000_subranges(cnr_gpu, cnr_golden, frm, to):
     deg, succ = cnr_gpu.decode_range(frm, to)

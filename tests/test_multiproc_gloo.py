@@ -24,7 +24,8 @@ def _worker(rank, world, port, n, seed, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     import webgraph_big_amd as W
-    from webgraph_big_amd import tools as T, shard as S
+    import tooling as T
+    from webgraph_big_amd import shard as S
     from oracle import bvg_oracle as O
     dist.init_process_group("gloo", rank=rank, world_size=world)
     st = T.synth_store(n, seed=seed, chunk_nodes=2048, threads=2)       # every rank holds the same shard bytes (weak scaling)

@@ -1,13 +1,16 @@
-"""CPU tooling (webgraph-big_amd/lib/libbvg_tools.so): the BVGraph *encoder* and synthetic graph
-generators used by tests and bench.py to manufacture inputs.  Not on the GPU hot path.
-Restates BVGraph.java:1595-1618, 1977-2159, 2216-2327 (see tools/bvg_store.cpp)."""
+"""CPU tooling (tooling/lib/libbvg_tools.so): the BVGraph *encoder* and the synthetic graph generators that tests and bench.py
+manufacture their inputs with.  Test and benchmark infrastructure: outside the product package, never on the GPU hot path, and
+held to the oracle's standard (it regenerates the reference's cnr-2000 fixture byte for byte, tests/test_store.py).
+Restates BVGraph.java:1595-1618, 1977-2159, 2216-2327 (see tooling/bvg_store.cpp)."""
 import ctypes as C
 import os
 import subprocess
 
 import numpy as np
 
-from ._abi import Params, default_params, GAMMA
+import webgraph_big_amd as _W        # (the ABI structs of the product package: the one definition of bvg_params)
+
+Params, default_params, GAMMA = _W.Params, _W.default_params, _W.GAMMA
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -44,8 +47,10 @@ def eu_like(**kw):
 
 
 def build(force=False):
+    if os.environ.get("BVG_TOOLS_LIB"):                      # an alternative build of the same source (tooling/Makefile `asan`: tests/test_sanitizers.py)
+        return os.environ["BVG_TOOLS_LIB"]
     so = os.path.join(_HERE, "lib", "libbvg_tools.so")
-    src = os.path.join(_HERE, "tools", "bvg_store.cpp")
+    src = os.path.join(_HERE, "bvg_store.cpp")
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "lib/libbvg_tools.so"])
     return so

@@ -19,7 +19,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/bvgraph_hip.h"
+#include "../include/bvgraph_hip.h"
 
 namespace {
 
