@@ -89,9 +89,10 @@ int bvg_decode_offsets(const uint8_t* obytes, size_t nbytes, int64_t nodes, int 
 
 /* BVGraph.load / loadMapped / loadOffline / loadSequential(basename) (BVG:1345-1464).  Reads
  * basename.properties/.graph[/.offsets], uploads to `device`.  BVG_LOAD_SEQUENTIAL / _OFFLINE need
- * no .offsets file: the index is then derived on the device by one sequential pass over the stream
- * (a single wavefront, ~10 M codes/s: fine for small graphs, minutes for billions of arcs — the same
- * order as the reference's own sequential scan; BVGraph -O / writeOffsets, BVG:2595-2609). */
+ * no .offsets file: the index is then derived on the device (BVGraph -O / writeOffsets, BVG:2595-2609) by chunk-parallel speculative
+ * walks iterated to the one consistent walk -- measured 0.4-10 s per GiB of stream on 0.25 GiB inputs, the fixed part being the
+ * regions that settle one 4 KiB chunk per round (profiles/r03_derive_bench.txt); windows > 127 and streams the parallel walk finds
+ * odd take one sequential pass of a single wavefront (~360 s per GiB). */
 int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out);
 /* Same from host memory.  offsets: nodes+1 bit positions or NULL (derive on device). */
 int bvg_open_mem(const bvg_params* p, const uint8_t* graph, uint64_t nbytes, const uint64_t* offsets, int device, bvg_graph** out);

@@ -323,6 +323,56 @@ def test_offsets_are_derived_when_absent(W, tools, oracle, tmp_path, cnr_csr):
     assert q2.scan()["arcs"] == st.stats["arcs"]
 
 
+def test_offsets_are_derived_by_the_chunk_parallel_walk(W, tools, capfd, monkeypatch):
+    """BVGraph -O (writeOffsets, BVGraph.java:2595-2609) by the chunk-parallel walk of csrc/bvg_derive.hip (the default since round 3):
+    speculative walks, one code per lane and step, iterated to the one consistent walk.  It must reproduce the encoder's offsets
+    exactly -- on a stream of thousands of chunks, without references, with other codings, with a window of 100, across a record
+    of 300 000 residuals (dozens of chunks that cannot fall into step by themselves) -- in far fewer rounds than there are chunks."""
+    monkeypatch.setenv("BVG_DEBUG", "1")
+    st = tools.synth_store(1 << 18, seed=3, synth=tools.eu_like(), threads=8)
+    big = tools.tile_host(st, 6)
+    capfd.readouterr()
+    g = W.BVGraph.from_memory(big.params, big.graph, None)
+    err = capfd.readouterr().err
+    assert "parallel walk ok" in err, err
+    rounds = int(err.split("parallel walk ok (")[1].split(" rounds")[0])
+    assert 2 <= rounds <= 1500, err                                          # (7 660 chunks: far fewer rounds than chunks)
+    assert np.array_equal(g.offsets(), big.offsets)
+    assert g.scan()["arcs"] == big.stats["arcs"]
+    g.close()
+    for kw in (dict(window_size=0, max_ref_count=0, min_interval_length=0), dict(residual_coding=1, outdegree_coding=1, reference_coding=2, block_count_coding=5, block_coding=1),
+               dict(residual_coding=7), dict(window_size=100, max_ref_count=20), dict(zeta_k=1, min_interval_length=2)):      # (Golomb residuals of a web graph are codes of thousands of bits: no walk derives those)
+        s2 = tools.synth_store(200000, seed=5, params=W.default_params(**kw), threads=4)
+        h = W.BVGraph.from_memory(s2.params, s2.graph, None)
+        assert np.array_equal(h.offsets(), s2.offsets), kw
+        h.close()
+    assert "parallel walk ok" in capfd.readouterr().err
+    # one giant record in the middle of ordinary ones
+    rng = np.random.default_rng(2)
+    n = 400000
+    lens = rng.integers(0, 9, n)
+    lo = np.maximum(np.arange(n) - 40, 0)
+    lists = [np.unique(lo[x] + rng.integers(0, 80, lens[x])) for x in range(n)]
+    lists = [l[l < n] for l in lists]
+    lists[2500] = np.unique(rng.integers(0, n, 600000))[:300000]
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.uint64)
+    s3 = tools.store((off, np.concatenate(lists).astype(np.int64)), W.default_params(), threads=4)
+    assert int(np.diff(s3.offsets.astype(np.int64)).max()) > 10 * 32768       # the record spans more than ten chunks
+    h = W.BVGraph.from_memory(s3.params, s3.graph, None)
+    assert np.array_equal(h.offsets(), s3.offsets)
+    h.close()
+    # a window beyond the ring of the parallel walk takes the sequential one
+    s4 = tools.synth_store(3000, seed=6, params=W.default_params(window_size=200, max_ref_count=3), threads=2)
+    capfd.readouterr()
+    h = W.BVGraph.from_memory(s4.params, s4.graph, None)
+    assert "not used" in capfd.readouterr().err and np.array_equal(h.offsets(), s4.offsets)
+    h.close()
+    # a truncated stream is still reported, not derived wrongly
+    cut = st.graph[:len(st.graph) // 2].copy()
+    with pytest.raises((W.EOFException, W.IllegalStateException)):
+        W.BVGraph.from_memory(st.params, cut, None)
+
+
 def _cpu_transpose(n, deg, succ):
     src = np.repeat(np.arange(n, dtype=np.int64), deg)
     order = np.argsort(succ, kind="stable")                       # stable: sources stay increasing inside every target

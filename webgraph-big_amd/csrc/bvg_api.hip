@@ -960,12 +960,11 @@ int open_common(const bvg_params* p, const uint8_t* h_graph, const void* d_graph
             unsigned* d_err = nullptr;
             HIPCHK(hipMalloc(&d_err, sizeof(unsigned)));
             HIPCHK(hipMemset(d_err, 0, sizeof(unsigned)));
-            // BVG_DERIVE_PAR=1 (opt-in, round 2): chunks walked speculatively and iterated to the one consistent walk (bvg_derive.hip);
-            // exact, but its lanes diverge field by field and regions that do not fall into step settle one chunk per round, so it is
-            // 0.7-17x the speed of the one-wavefront walk depending on the graph (profiles/r02/derive_bench.py).  Default and fall-back
-            // (windows > 64, records > 64 Mbit, any error, so that the error bits are those of the plain walk): the sequential walk.
+            // Default: the chunk-parallel walk of bvg_derive.hip (round 3: one code per lane and step, only changed chunks re-walked).
+            // Fall-back -- windows > 127, any oddity in the stream, BVG_DERIVE_SEQ=1 -- is the one-wavefront sequential walk, whose error
+            // bits are the documented ones.
             int rounds = 0;
-            int pr = !(kExperimental && knob("BVG_DERIVE_PAR")) ? -1 : derive_offsets_parallel(sh->d_graph, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr, &rounds);
+            int pr = knob("BVG_DERIVE_SEQ") ? -1 : derive_offsets_parallel(sh->d_graph, nbytes, n, p->window_size, p->min_interval_length, codings_of(*p), d_wide, d_err, nullptr, &rounds);
             if (pr == 0) {
                 unsigned e0 = 0;
                 if (hipMemcpy(&e0, d_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipFree(d_err); release_shared(sh); return BVG_E_HIP; }

@@ -101,9 +101,14 @@ void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s);
 size_t scan_static_lds();
 
+// the offsets index from a bare .graph in parallel (bvg_derive.hip): chunks of the stream walked speculatively, one code per lane and step, and iterated
+// to the one consistent walk; 0 = done (err[0] != 0 on a bad stream), < 0 = not applicable / gave up: fall back to launch_derive_offsets
+int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod, uint64_t* offsets, unsigned* err,
+                            hipStream_t s, int* rounds);
+
 // Experiments that lost to the row kernel are compiled only by `make experimental` (-DBVG_EXPERIMENTAL): the row kernel
 // with one workgroup of nw wavefronts per block sharing the pool (bvg_rows_wg.hip), the streaming data-flow kernel
-// (bvg_stream.hip), the flow scan kernel (bvg_flow.hip), the chunk-parallel offsets derivation (bvg_derive.hip).
+// (bvg_stream.hip), the flow scan kernel (bvg_flow.hip), 
 #ifdef BVG_EXPERIMENTAL
 constexpr bool kExperimental = true;
 void launch_rows_wg_decode(const DecodeArgs& a, uint32_t nblocks, int nw, hipStream_t s);
@@ -112,8 +117,6 @@ void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool
 size_t flow_scratch_bytes_per_wave(int window);
 size_t flow_lds_bytes(uint32_t ring_cap);
 void launch_flow_scan(const DecodeArgs& a, uint32_t nblocks, uint32_t waves, void* scratch, uint32_t ring_cap, hipStream_t s);
-int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, int window, int min_interval, Codings cod, uint64_t* offsets, unsigned* err,
-                            hipStream_t s, int* rounds);
 #else
 constexpr bool kExperimental = false;
 inline void launch_rows_wg_decode(const DecodeArgs&, uint32_t, int, hipStream_t) {}
@@ -121,7 +124,6 @@ inline size_t rows_wg_static_lds(int) { return 0; }
 inline size_t flow_scratch_bytes_per_wave(int) { return 0; }
 inline size_t flow_lds_bytes(uint32_t) { return 0; }
 inline void launch_flow_scan(const DecodeArgs&, uint32_t, uint32_t, void*, uint32_t, hipStream_t) {}
-inline int derive_offsets_parallel(const uint8_t*, uint64_t, int64_t, int, int, Codings, uint64_t*, unsigned*, hipStream_t, int*) { return -1; }
 #endif
 
 // tier 2a (bvg_giant.hip): blocks with lists / records too large for LDS, one 256-thread workgroup per block, work areas as for the
