@@ -125,6 +125,10 @@ int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out);
  * to == from+1 is successors(x) (BVG:860-867).  If succ_cap is too small returns BVG_E_CAPACITY
  * with *n_succ = required size (succ may be NULL to query).  outdeg may be NULL. */
 int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
+/* Same with the successors as 32-bit ids: graphs of at most 2^32 nodes (ids + node base below 2^32; otherwise BVG_E_UNSUPPORTED), host
+ * buffers only.  Half the bytes over PCIe, which bounds this path; the caller widens (NodeIterator.successorBigArray() hands out
+ * longs, NodeIterator.java:80-96).  A missing successor of a malformed stream (-1 above) reads 0xFFFFFFFF. */
+int bvg_decode_range32(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, uint32_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Same, successor / outdegree buffers in device memory (stay in HBM for a downstream kernel). */
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Page-locked host memory for the buffers handed to bvg_decode_range / bvg_successors_batch: device -> host copies into it run

@@ -56,8 +56,8 @@ def main():
     it.next_long(); b0, deg, cum, succ = it.batch()
     assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc)
     it.close()
-    out["sequential_host"] = {"edges_per_s": m / t, "nodes_per_s": n / t, "s_per_pass": t, "host_GB_per_s": (8.0 * m + 4.0 * n) / t / 1e9,
-                              "batch_nodes": args.batch_nodes, "note": "NodeIterator batches, successors as int64 in page-locked host memory; decode of batch i+1 overlaps the walk over batch i"}
+    out["sequential_host"] = {"edges_per_s": m / t, "nodes_per_s": n / t, "s_per_pass": t, "host_GB_per_s": (succ.dtype.itemsize * m + 4.0 * n) / t / 1e9,
+                              "batch_nodes": args.batch_nodes, "note": "NodeIterator batches, successors as uint32 (ids below 2^32; int64 otherwise) in page-locked host memory; decode of batch i+1 overlaps the walk over batch i"}
     # the same without the pipeline and with pageable buffers (the round-1 path)
     t0 = time.perf_counter(); tot = 0
     for lo in range(0, n, args.batch_nodes):

@@ -217,6 +217,34 @@ def test_wide_ids_beyond_32_bits(W, tools, oracle):
     assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]
 
 
+def test_successors_as_32_bit_ids_for_the_host_path(W, small, oracle):
+    """bvg_decode_range32: the same lists as bvg_decode_range, ids as uint32 (what the NodeIterator mirror moves over PCIe and widens,
+    NodeIterator.java:80-96); refused when an id could pass 2^32."""
+    g, og, lists, st = small
+    n = g.num_nodes()
+    deg, succ = g.decode_range(0, n)
+    d32, s32 = g.decode_range32(0, n)
+    assert s32.dtype == np.uint32 and np.array_equal(d32, deg) and np.array_equal(s32.astype(np.int64), succ)
+    d32, s32 = g.decode_range32(n // 3, n // 2)
+    od, os_ = og.decode_range(n // 3, n // 2)
+    assert np.array_equal(d32, od) and np.array_equal(s32, os_)
+    h = g.copy()
+    h.set_node_base((1 << 32) - n)                                      # the largest base that still fits
+    _, s32 = h.decode_range32(0, 100)
+    assert np.array_equal(s32.astype(np.int64), og.decode_range(0, 100)[1] + ((1 << 32) - n))
+    h.set_node_base((1 << 32) - n + 1)
+    with pytest.raises(W.UnsupportedOperationException):
+        h.decode_range32(0, 100)
+    it = W.NodeIterator(h, 0, batch_nodes=512)                          # beyond 2^32 the iterator moves int64
+    it.next_long()
+    assert it.successor_array().dtype == np.int64 and np.array_equal(it.successor_array(), og.successors(0) + ((1 << 32) - n + 1))
+    it.close(); h.close()
+    it = W.NodeIterator(g, 5, batch_nodes=300)                          # below: uint32 batches, widened per node
+    x = it.next_long()
+    assert it.batch()[3].dtype == np.uint32 and it.successor_array().dtype == np.int64 and np.array_equal(it.successor_array(), og.successors(x))
+    it.close()
+
+
 def test_mosaic_is_the_cycle_of_its_bases(W, tools, oracle):
     """bvg_mosaic: the streams of several DIFFERENT graphs back to back, the cycle repeated (the bench's workload): equals the host
     twin tools.mosaic_host bit for bit, decodes to the bases' lists shifted by their first node, checksums add up."""

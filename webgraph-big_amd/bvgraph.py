@@ -14,6 +14,7 @@ the first call that needs the device.
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -112,6 +113,7 @@ def lib():
         L.bvg_outdegrees.argtypes = [vp, i64, i64, vp]
         L.bvg_decode_range.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_decode_range_dev.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
+        L.bvg_decode_range32.argtypes = [vp, i64, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_scan.argtypes = [vp, i64, i64, C.POINTER(ScanResult)]
         L.bvg_successors_batch.argtypes = [vp, vp, i64, vp, vp, u64, C.POINTER(u64)]
         L.bvg_host_alloc.argtypes = [C.c_size_t]; L.bvg_host_alloc.restype = vp
@@ -246,14 +248,18 @@ class PinnedArray:
 _PIN_CACHE = {}          # nbytes -> [PinnedArray]: page-locking memory costs ~0.3 s per GiB, so iterators hand their buffers on
 _PIN_CACHE_LIMIT = 8 << 30
 _pin_cached = 0
+_PIN_LOCK = threading.Lock()   # iterators recycle buffers from their helper threads too
 
 
 def _pinned(count, dtype):
     global _pin_cached
     nbytes = max(int(count), 1) * np.dtype(dtype).itemsize
-    lst = _PIN_CACHE.get(nbytes)
-    if lst:
-        pa = lst.pop(); _pin_cached -= nbytes
+    with _PIN_LOCK:
+        lst = _PIN_CACHE.get(nbytes)
+        pa = lst.pop() if lst else None
+        if pa is not None:
+            _pin_cached -= nbytes
+    if pa is not None:
         pa.dtype = np.dtype(dtype)
         pa.array = np.ctypeslib.as_array(C.cast(pa._p, C.POINTER(C.c_uint8)), shape=(nbytes,)).view(pa.dtype)
         return pa
@@ -261,12 +267,16 @@ def _pinned(count, dtype):
 
 
 def _unpin(pa):
+    """Hands a page-locked buffer back.  Views of it that a caller kept (successor_array(), batch()) are valid only until the
+    iterator moves on (NodeIterator.java:80-96: "the returned array may be reused"): copy what must outlive that."""
     global _pin_cached
     if pa is None or not getattr(pa, "_p", None):
         return
-    if _pin_cached + pa.nbytes <= _PIN_CACHE_LIMIT:
-        _PIN_CACHE.setdefault(pa.nbytes, []).append(pa); _pin_cached += pa.nbytes
-    else:
+    with _PIN_LOCK:
+        keep = _pin_cached + pa.nbytes <= _PIN_CACHE_LIMIT
+        if keep:
+            _PIN_CACHE.setdefault(pa.nbytes, []).append(pa); _pin_cached += pa.nbytes
+    if not keep:
         pa.close()
 
 
@@ -277,17 +287,21 @@ class _BatchSlot:
     def __init__(self, graph, batch_nodes):
         self.g = graph.copy()
         self.deg = _pinned(batch_nodes, np.int32)
-        self.succ = _pinned(max(1024, 32 * batch_nodes), np.int64)
+        # graphs whose ids fit 32 bits cross PCIe as uint32 (bvg_decode_range32): the transfer bounds this path, so half the bytes is
+        # twice the rate; successor_array() widens to the longs of NodeIterator.successorBigArray()
+        self.dt = np.uint32 if graph.num_nodes() + graph.node_base() <= (1 << 32) else np.int64
+        self.succ = _pinned(max(1024, 32 * batch_nodes), self.dt)
         self.lo = self.hi = 0
         self.n_succ = 0
 
     def decode(self, lo, hi):
         need = C.c_uint64(0)
+        fn = lib().bvg_decode_range32 if self.dt is np.uint32 else lib().bvg_decode_range
         while True:
-            st = lib().bvg_decode_range(self.g._h, lo, hi, self.deg.array.ctypes.data, self.succ.array.ctypes.data, len(self.succ.array), C.byref(need))
+            st = fn(self.g._h, lo, hi, self.deg.array.ctypes.data, self.succ.array.ctypes.data, len(self.succ.array), C.byref(need))
             if st == _abi.E_CAPACITY:
                 _unpin(self.succ)
-                self.succ = _pinned(((int(need.value) + int(need.value) // 4) + 0xFFFFF) & ~0xFFFFF, np.int64)
+                self.succ = _pinned(((int(need.value) + int(need.value) // 4) + 0xFFFFF) & ~0xFFFFF, self.dt)
                 continue
             _check(st, "decode_range(%d,%d)" % (lo, hi))
             break
@@ -389,13 +403,15 @@ class NodeIterator:
         """successorBigArray(): view valid until the next next_long() (NodeIterator.java:80-96)."""
         self._require_started()
         i = self._curr - self._b0
-        return self._succ[self._cum[i]:self._cum[i + 1]]
+        v = self._succ[self._cum[i]:self._cum[i + 1]]
+        return v if v.dtype == np.int64 else v.astype(np.int64)        # (ids that crossed PCIe as uint32 are widened here)
 
     successorBigArray = successor_array
 
     def batch(self):
-        """The whole current batch at once: (first node, outdeg int32[], cum int64[], succ int64[]) — views valid until the next
-        next_long() that leaves the batch (what a bulk consumer walks instead of one node at a time)."""
+        """The whole current batch at once: (first node, outdeg int32[], cum int64[], succ) — views valid until the next next_long()
+        that leaves the batch (what a bulk consumer walks instead of one node at a time).  succ is uint32 for graphs whose ids fit
+        32 bits (as it crossed PCIe), int64 otherwise."""
         self._require_started()
         return self._b0, self._deg, self._cum, self._succ
 
@@ -542,10 +558,16 @@ class BVGraph:
         h = C.c_void_p()
         _check(lib().bvg_copy(self._h, C.byref(h)), "copy")
         g = BVGraph(h); g._basename = self._basename
+        if self.node_base():
+            g.set_node_base(self.node_base())                               # (a flyweight answers in the same id space)
         return g
 
     def set_node_base(self, base):
         _check(lib().bvg_set_node_base(self._h, base), "set_node_base")
+        self._node_base = int(base)
+
+    def node_base(self):
+        return getattr(self, "_node_base", 0)
 
     def set_tuning(self, block_bits=0, force_wide=False, force_slow=False, stream=False, grab_threshold=0, legacy=False):
         """stream=True selects the experimental streaming data-flow kernel (bvg_stream.hip) as tier 0."""
@@ -583,6 +605,23 @@ class BVGraph:
                 cap = int(need.value)
                 continue
             _check(st, "decode_range(%d,%d)" % (frm, to))
+            return deg[:cnt], succ[:need.value]
+
+    def decode_range32(self, frm, to):
+        """decode_range with the successors as uint32 (bvg_decode_range32: graphs whose ids fit 32 bits; half the bytes over PCIe)."""
+        if frm < 0 or to > self.num_nodes() or frm > to:
+            raise IllegalArgumentException(_abi.E_ARG, "decode_range32(%d,%d)" % (frm, to))
+        cnt = to - frm
+        deg = np.empty(max(cnt, 1), dtype=np.int32)
+        need = C.c_uint64(0)
+        cap = max(1024, 16 * cnt)
+        while True:
+            succ = np.empty(cap, dtype=np.uint32)
+            st = lib().bvg_decode_range32(self._h, frm, to, deg.ctypes.data, succ.ctypes.data, cap, C.byref(need))
+            if st == _abi.E_CAPACITY:
+                cap = int(need.value)
+                continue
+            _check(st, "decode_range32(%d,%d)" % (frm, to))
             return deg[:cnt], succ[:need.value]
 
     def successors_batch(self, nodes):

@@ -1208,9 +1208,10 @@ static int dr_ensure(bvg_graph* g, size_t bytes) {
     return 0;
 }
 
-static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t cap, uint64_t* n_succ, bool dev) {
+static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t cap, uint64_t* n_succ, bool dev, bool narrow = false) {
     if (!g) return BVG_E_ARG;
     Shared* sh = g->sh;
+    if (narrow && (dev || (uint64_t)sh->p.nodes + g->node_base > (1ull << 32))) return BVG_E_UNSUPPORTED;   // 32-bit ids: host path, every id below 2^32
     if (from < 0 || to > sh->p.nodes || from > to) return BVG_E_ARG;               // BVG:863,1000,1128
     if (from == to) { if (n_succ) *n_succ = 0; return 0; }
     HIPCHK(hipSetDevice(sh->device));
@@ -1235,9 +1236,10 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
     }
     int64_t* d_succ = succ;
     if (!dev) {
-        if (o_succ + (size_t)(total ? total : 1) * sizeof(int64_t) > g->dr_ws_bytes) {
+        const size_t per = sizeof(int64_t) + (narrow ? sizeof(uint32_t) : 0);
+        if (o_succ + (size_t)(total ? total : 1) * per + 256 > g->dr_ws_bytes) {
             // growing moves the workspace: the prefix sums are recomputed rather than copied (two tiny kernels)
-            rc = dr_ensure(g, o_succ + (size_t)(total ? total : 1) * sizeof(int64_t)); if (rc) return rc;
+            rc = dr_ensure(g, o_succ + (size_t)(total ? total : 1) * per + 256); if (rc) return rc;
             d_deg = (int32_t*)at(o_deg); d_cum = (uint64_t*)at(o_cum);
             launch_outdegrees(sh->d_graph, sh->nbytes, sh->offs, from, to, sh->p.outdegree_coding, d_deg, nullptr, g->stream);
             launch_exclusive_scan(d_deg, d_cum, cnt, (uint64_t*)at(o_tmp), g->stream);
@@ -1247,7 +1249,11 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
     rc = run_decode(g, from, to, true, d_cum, d_succ, d_deg, nullptr);
     if (rc == 0 && !dev) {
         // device -> host on the handle's stream: at PCIe rate when the caller's buffers are page-locked (bvg_host_alloc)
-        if (total) HIPCHK(hipMemcpyAsync(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
+        if (total && narrow) {
+            uint32_t* d32 = (uint32_t*)at(o_succ + al((size_t)total * sizeof(int64_t)));
+            launch_narrow_succ(d_succ, d32, total, g->stream);
+            HIPCHK(hipMemcpyAsync(succ, d32, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream));
+        } else if (total) HIPCHK(hipMemcpyAsync(succ, d_succ, (size_t)total * sizeof(int64_t), hipMemcpyDeviceToHost, g->stream));
         if (outdeg) HIPCHK(hipMemcpyAsync(outdeg, d_deg, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost, g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
     }
@@ -1256,6 +1262,9 @@ static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* ou
 
 int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
     return guarded([&] { return decode_range_impl(g, from, to, outdeg, succ, succ_cap, n_succ, false); });
+}
+int bvg_decode_range32(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, uint32_t* succ, uint64_t succ_cap, uint64_t* n_succ) {
+    return guarded([&] { return decode_range_impl(g, from, to, outdeg, (int64_t*)succ, succ_cap, n_succ, false, true); });
 }
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ) {
     return guarded([&] { return decode_range_impl(g, from, to, (int32_t*)d_outdeg, (int64_t*)d_succ, succ_cap, n_succ, true); });

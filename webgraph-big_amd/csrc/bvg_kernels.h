@@ -48,6 +48,7 @@ struct Offsets {
 };
 // packs entries [first, first + count) of an index (first: a multiple of 2^kOffShift; src[0] is entry `first`); *overflow != 0 if a distance does not fit
 void launch_pack_offsets(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow, hipStream_t s);
+void launch_narrow_succ(const int64_t* in, uint32_t* out, uint64_t n, hipStream_t s);   // int64 successors -> uint32 (host path of graphs with <= 2^32 nodes)
 void launch_unpack_offsets(Offsets o, int64_t first, int64_t count, uint64_t* dst, hipStream_t s);
 
 struct DecodeArgs {

@@ -532,6 +532,12 @@ __global__ void mosaic_offsets_kernel(MosaicSrc m, int64_t tot, uint32_t* dst_lo
     }
 }
 
+// successors as 32-bit ids for the host path of graphs with at most 2^32 nodes (half the bytes over PCIe): -1 (a short list of a
+// malformed stream) becomes 0xFFFFFFFF
+__global__ void narrow_succ_kernel(const int64_t* in, uint32_t* out, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = (uint32_t)in[i];
+}
+
 __global__ void pack_offsets_kernel(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t x = first + j;
@@ -647,6 +653,10 @@ void launch_mosaic_graph(const MosaicSrc& m, uint8_t* dst, uint64_t dst_bytes, i
 void launch_mosaic_offsets(const MosaicSrc& m, int64_t cycles, uint32_t* dst_lo, uint64_t* dst_hi, unsigned* overflow, hipStream_t s) {
     const int64_t tot = m.cycle_nodes * cycles;
     hipLaunchKernelGGL(mosaic_offsets_kernel, dim3((unsigned)std::min<int64_t>((tot + 256) / 256, 1 << 22)), dim3(256), 0, s, m, tot, dst_lo, dst_hi, overflow);
+}
+void launch_narrow_succ(const int64_t* in, uint32_t* out, uint64_t n, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(narrow_succ_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20)), dim3(256), 0, s, in, out, n);
 }
 void launch_pack_offsets(const uint64_t* src, int64_t first, int64_t count, uint32_t* lo, uint64_t* hi, unsigned* overflow, hipStream_t s) {
     if (count <= 0) return;
