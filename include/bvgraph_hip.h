@@ -154,6 +154,12 @@ int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
 /* Builds that index for the blocks of [from,to) now (0, nodes = the whole graph) instead of inside the first scan; a no-op when
  * they are covered already.  entries / bytes (either may be NULL) report what the index of the graph holds afterwards. */
 int bvg_build_index(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, uint64_t* bytes);
+/* The device index on disk: the block plan and the residual skip index (with its validation marks) as they stand, written to `path` and
+ * loaded back by a later process instead of rebuilt (cf. the reference's cached offsets big list, basename.obl, BVG:1545-1555).
+ * bvg_open() loads basename.bvgidx by itself when it exists and is not older than basename.graph; a file that does not belong to
+ * the graph (size, parameters, block size, a fingerprint of the stream) is refused with BVG_E_IO and the index is built as usual. */
+int bvg_save_index(bvg_graph* g, const char* path);
+int bvg_load_index(bvg_graph* g, const char* path);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
  * IG:405-436; cf. algo/HyperBall.java:748-768): bounds[0..k], bounds[0]=0, bounds[k]=nodes. */
 int bvg_split_by_bits(bvg_graph* g, int k, int64_t* bounds);

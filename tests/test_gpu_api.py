@@ -217,6 +217,45 @@ def test_wide_ids_beyond_32_bits(W, tools, oracle):
     assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"]
 
 
+def test_device_index_is_saved_and_loaded_back(W, tools, oracle, tmp_path, capfd, monkeypatch):
+    """basename.bvgidx (bvg_save_index): the block plan and the residual skip index of one process are what the next one scans with --
+    no index-building passes, the same lean blocks, the same checksum (cf. the cached offsets big list of BVGraph.java:1545-1555); a
+    file that is older than the graph, or belongs to another graph, is ignored / refused."""
+    import os, time
+    monkeypatch.setenv("BVG_DEBUG", "1"); monkeypatch.setenv("BVG_EMIT", "1")
+    st = tools.synth_store(30000, seed=8, synth=tools.eu_like(mean_deg=70.0), threads=4)
+    base = str(tmp_path / "g"); st.write(base)
+    og = oracle.Graph.load(base); o = og.scan()
+    g = W.BVGraph.load(base)
+    r1 = g.scan(); r1 = g.scan()
+    assert (r1["arcs"], r1["chk"]) == (o["arcs"], o["chk"]) and r1["index_entries"] > 0 and r1["lean_blocks"] > 0
+    assert g.save_index() == base + ".bvgidx" and os.path.getsize(base + ".bvgidx") > 6 * r1["index_entries"]
+    g.close()
+    capfd.readouterr()
+    h = W.BVGraph.load(base)                                            # picks the file up
+    r2 = h.scan()
+    err = capfd.readouterr().err
+    assert "index loaded from" in err and "residual skip index: blocks" not in err, err
+    assert (r2["arcs"], r2["chk"], r2["index_entries"], r2["lean_blocks"]) == (r1["arcs"], r1["chk"], r1["index_entries"], r1["lean_blocks"])
+    d1, s1 = h.decode_range(100, 5000); d0, s0 = og.decode_range(100, 5000)
+    assert np.array_equal(d1, d0) and np.array_equal(s1, s0)
+    h.close()
+    # an index of another graph is refused; one older than the graph is not even tried
+    st2 = tools.synth_store(30000, seed=9, synth=tools.eu_like(mean_deg=70.0), threads=4)
+    base2 = str(tmp_path / "h"); st2.write(base2)
+    q = W.BVGraph.load(base2)
+    with pytest.raises(W.IOException):
+        q.load_index(base + ".bvgidx")
+    assert q.scan()["arcs"] == st2.stats["arcs"]
+    q.close()
+    t = time.time() + 100
+    os.utime(base + ".graph", (t, t))
+    capfd.readouterr()
+    h = W.BVGraph.load(base)
+    assert h.scan()["chk"] == o["chk"] and "index loaded from" not in capfd.readouterr().err
+    h.close()
+
+
 def test_successors_as_32_bit_ids_for_the_host_path(W, small, oracle):
     """bvg_decode_range32: the same lists as bvg_decode_range, ids as uint32 (what the NodeIterator mirror moves over PCIe and widens,
     NodeIterator.java:80-96); refused when an id could pass 2^32."""

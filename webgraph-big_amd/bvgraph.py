@@ -145,6 +145,8 @@ def lib():
         L.bvg_strerror.argtypes = [C.c_int]; L.bvg_strerror.restype = C.c_char_p
         L.bvg_arc_mix.argtypes = [u64, u64]; L.bvg_arc_mix.restype = u64
         L.bvg_build_index.argtypes = [vp, i64, i64, C.POINTER(u64), C.POINTER(u64)]
+        L.bvg_save_index.argtypes = [vp, C.c_char_p]
+        L.bvg_load_index.argtypes = [vp, C.c_char_p]
         if L.bvg_abi_version() != 2:
             raise ImportError("libbvgraph_hip.so ABI mismatch")
         _LIB = L
@@ -727,6 +729,16 @@ class BVGraph:
         e = C.c_uint64(); b = C.c_uint64()
         _check(lib().bvg_build_index(self._h, frm, to, C.byref(e), C.byref(b)), "build_index(%d,%d)" % (frm, to))
         return int(e.value), int(b.value)
+
+    def save_index(self, path=None):
+        """Writes the device index (block plan + residual skip index) to `path` (default: basename.bvgidx, which load() picks up)."""
+        path = path or (self._basename + ".bvgidx")
+        _check(lib().bvg_save_index(self._h, os.fsencode(path)), "save_index(%s)" % path)
+        return path
+
+    def load_index(self, path):
+        """Loads an index written by save_index(); IOException if the file does not belong to this graph."""
+        _check(lib().bvg_load_index(self._h, os.fsencode(path)), "load_index(%s)" % path)
 
     def scan(self, frm=0, to=None):
         """Full sequential successor scan consumed on chip (SpeedTest.java:127-141): dict of bvg_scan_result."""

@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/stat.h>
+
 #include "bvg_kernels.h"
 
 using namespace bvg;
@@ -239,6 +241,8 @@ int ensure_device(int device) {
     return 0;
 }
 
+uint64_t next_plan_version() { static std::atomic<uint64_t> v{1}; return v.fetch_add(1); }
+
 // Builds the block plan: boundaries at ~equal compressed bits + per-block halo masks.
 int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
     Shared* sh = g->sh;
@@ -298,8 +302,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
                 (void)hipFree(d_maxd);
                 if (e2 != hipSuccess) return BVG_E_HIP;
             }
-            static std::atomic<uint64_t> plan_versions{1};
-            plan.version = plan_versions.fetch_add(1);
+            plan.version = next_plan_version();
             return publish();
         }
         // merge blocks: drop un-cuttable boundaries (the halo of a kept boundary does not depend on the others)
@@ -1002,6 +1005,122 @@ template <typename F> static int guarded(F&& f) {
     catch (...) { return BVG_E_STATE; }
 }
 
+// ---- the device index on disk (basename.bvgidx) ----
+// What a first scan builds -- the block plan (boundaries, halos, largest lists) and the residual skip index with its validation marks
+// -- written next to the graph so that the next process loads it instead of scanning the graph twice (the reference caches its own
+// index the same way: the .obl file of the offsets big list, checked against the file it was built from, BVG:1545-1555).  The file is
+// tied to the graph by size, parameters and a fingerprint of the stream's first and last 64 KiB.
+struct IndexHeader {
+    char magic[8]; uint32_t version, block_bits; uint64_t graph_bytes, total_bits; int64_t nodes; uint64_t fingerprint;
+    uint32_t window, wide, nblk, has_skip, skip_lo, skip_hi; uint64_t skip_total;
+};
+static const char kIndexMagic[8] = {'B', 'V', 'G', 'I', 'D', 'X', '1', 0};
+
+static int graph_fingerprint(const Shared* sh, uint64_t* out) {
+    const uint64_t piece = 65536, n = sh->nbytes;
+    std::vector<uint8_t> buf;
+    const uint64_t a = std::min<uint64_t>(piece, n), b = n > piece ? std::min<uint64_t>(piece, n - a) : 0;
+    buf.resize((size_t)(a + b));
+    if (a) HIPCHK(hipMemcpy(buf.data(), sh->d_graph, (size_t)a, hipMemcpyDeviceToHost));
+    if (b) HIPCHK(hipMemcpy(buf.data() + a, sh->d_graph + (n - b), (size_t)b, hipMemcpyDeviceToHost));
+    uint64_t h = 1469598103934665603ull ^ n;                              // FNV-1a
+    for (uint8_t c : buf) { h ^= c; h *= 1099511628211ull; }
+    *out = h;
+    return 0;
+}
+static bool put_dev(FILE* f, const void* d, size_t bytes) {               // device array -> file, in pieces
+    std::vector<uint8_t> buf(std::min<size_t>(bytes ? bytes : 1, (size_t)64 << 20));
+    for (size_t o = 0; o < bytes; o += buf.size()) {
+        const size_t k = std::min(buf.size(), bytes - o);
+        if (hipMemcpy(buf.data(), (const char*)d + o, k, hipMemcpyDeviceToHost) != hipSuccess || fwrite(buf.data(), 1, k, f) != k) return false;
+    }
+    return true;
+}
+static bool get_dev(FILE* f, void* d, size_t bytes) {                     // file -> device array
+    std::vector<uint8_t> buf(std::min<size_t>(bytes ? bytes : 1, (size_t)64 << 20));
+    for (size_t o = 0; o < bytes; o += buf.size()) {
+        const size_t k = std::min(buf.size(), bytes - o);
+        if (fread(buf.data(), 1, k, f) != k || hipMemcpy((char*)d + o, buf.data(), k, hipMemcpyHostToDevice) != hipSuccess) return false;
+    }
+    return true;
+}
+
+static int save_index_impl(bvg_graph* g, const char* path) {
+    if (!g || !path) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    HIPCHK(hipSetDevice(sh->device));
+    std::shared_ptr<Plan> plp;
+    int r = build_plan(g, block_bits_of(g), plp); if (r) return r;
+    const Plan& pl = *plp;
+    std::shared_ptr<SkipIndex> ix = std::atomic_load(&plp->skip);
+    IndexHeader h{};
+    memcpy(h.magic, kIndexMagic, 8); h.version = 1; h.block_bits = pl.block_bits; h.graph_bytes = sh->nbytes; h.total_bits = sh->total_bits; h.nodes = sh->p.nodes;
+    r = graph_fingerprint(sh, &h.fingerprint); if (r) return r;
+    h.window = (uint32_t)sh->p.window_size; h.nblk = pl.nblk;
+    if (ix) { h.has_skip = 1; h.wide = ix->wide ? 1u : 0u; h.skip_lo = ix->blk_lo; h.skip_hi = ix->blk_hi; h.skip_total = ix->total; }
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return BVG_E_IO;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    const size_t nb = pl.nblk;
+    ok = ok && fwrite(pl.h_first.data(), 8, nb + 1, f) == nb + 1 && (pl.h_maxd.size() == nb) && fwrite(pl.h_maxd.data(), 4, nb, f) == nb;
+    ok = ok && put_dev(f, pl.d_halo, nb * 4) && put_dev(f, pl.d_mask, nb * 8);
+    if (ok && ix) {
+        ok = fwrite(ix->h_first.data(), 8, nb + 1, f) == nb + 1 && fwrite(ix->h_fmt.data(), 1, nb, f) == nb;
+        ok = ok && put_dev(f, ix->d_bit, (size_t)ix->total * 2) && put_dev(f, ix->d_val, (size_t)ix->total * (ix->wide ? 8 : 4));
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return BVG_E_IO; }
+    return 0;
+}
+
+// BVG_E_IO: no such file / not an index of this graph (the caller then simply builds the index as usual)
+static int load_index_impl(bvg_graph* g, const char* path) {
+    if (!g || !path) return BVG_E_ARG;
+    Shared* sh = g->sh;
+    HIPCHK(hipSetDevice(sh->device));
+    FILE* f = fopen(path, "rb");
+    if (!f) return BVG_E_IO;
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    IndexHeader h{};
+    uint64_t fp = 0;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kIndexMagic, 8) != 0 || h.version != 1) return BVG_E_IO;
+    int r = graph_fingerprint(sh, &fp); if (r) return r;
+    if (h.graph_bytes != sh->nbytes || h.total_bits != sh->total_bits || h.nodes != sh->p.nodes || h.window != (uint32_t)sh->p.window_size || h.fingerprint != fp ||
+        h.block_bits != block_bits_of(g) || h.nblk == 0 || (uint64_t)h.nblk > (uint64_t)sh->p.nodes) return BVG_E_IO;
+    const size_t nb = h.nblk;
+    std::shared_ptr<Plan> np = std::make_shared<Plan>();
+    Plan& pl = *np;
+    pl.device = sh->device; pl.block_bits = h.block_bits; pl.nblk = h.nblk; pl.h_first.resize(nb + 1); pl.h_maxd.resize(nb);
+    if (fread(pl.h_first.data(), 8, nb + 1, f) != nb + 1 || fread(pl.h_maxd.data(), 4, nb, f) != nb) return BVG_E_IO;
+    if (pl.h_first[0] != 0 || pl.h_first[nb] != (uint64_t)sh->p.nodes) return BVG_E_IO;
+    for (size_t i = 0; i < nb; i++) if (pl.h_first[i] >= pl.h_first[i + 1]) return BVG_E_IO;
+    if (hipMalloc(&pl.d_first, (nb + 1) * 8) != hipSuccess || hipMalloc(&pl.d_halo, nb * 4) != hipSuccess || hipMalloc(&pl.d_mask, nb * 8) != hipSuccess) { (void)hipGetLastError(); return BVG_E_NOMEM; }
+    HIPCHK(hipMemcpy(pl.d_first, pl.h_first.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
+    if (!get_dev(f, pl.d_halo, nb * 4) || !get_dev(f, pl.d_mask, nb * 8)) return BVG_E_IO;
+    if (h.has_skip) {
+        if (h.skip_lo >= h.skip_hi || h.skip_hi > h.nblk) return BVG_E_IO;
+        std::shared_ptr<SkipIndex> ix = std::make_shared<SkipIndex>();
+        ix->device = sh->device; ix->blk_lo = h.skip_lo; ix->blk_hi = h.skip_hi; ix->total = h.skip_total; ix->wide = h.wide != 0;
+        ix->h_first.resize(nb + 1); ix->h_fmt.resize(nb);
+        if (fread(ix->h_first.data(), 8, nb + 1, f) != nb + 1 || fread(ix->h_fmt.data(), 1, nb, f) != nb) return BVG_E_IO;
+        if (ix->h_first[nb] != ix->total) return BVG_E_IO;
+        for (size_t i = 0; i < nb; i++) if (ix->h_first[i] > ix->h_first[i + 1]) return BVG_E_IO;
+        const size_t vb = ix->wide ? 8 : 4;
+        if (hipMalloc(&ix->d_first, (nb + 1) * 8) != hipSuccess || hipMalloc(&ix->d_bit, (size_t)ix->total * 2 + 16) != hipSuccess || hipMalloc(&ix->d_fmt, nb) != hipSuccess ||
+            hipMalloc(&ix->d_val, (size_t)ix->total * vb + 16) != hipSuccess) { (void)hipGetLastError(); return BVG_E_NOMEM; }
+        HIPCHK(hipMemcpy(ix->d_first, ix->h_first.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ix->d_fmt, ix->h_fmt.data(), nb, hipMemcpyHostToDevice));
+        if (!get_dev(f, ix->d_bit, (size_t)ix->total * 2) || !get_dev(f, ix->d_val, (size_t)ix->total * vb)) return BVG_E_IO;
+        std::atomic_store(&pl.skip, ix);
+    }
+    pl.version = next_plan_version();
+    std::lock_guard<std::mutex> lk(sh->mu);
+    sh->plans.clear(); sh->plans[pl.block_bits] = np;
+    if (dbg_on()) fprintf(stderr, "[bvg] index loaded from %s: %u blocks, %llu skip entries\n", path, h.nblk, (unsigned long long)h.skip_total);
+    return 0;
+}
+
 extern "C" {
 
 int bvg_abi_version(void) { return BVG_ABI_VERSION; }
@@ -1116,7 +1235,15 @@ int bvg_open(const char* basename, int load_mode, int device, bvg_graph** out) {
     }
     std::vector<uint64_t> offsets((size_t)p.nodes + 1);
     r = bvg_decode_offsets(offs.data(), offs.size(), p.nodes, p.offset_coding, offsets.data()); if (r) return r;
-    return open_common(&p, graph.data(), nullptr, graph.size(), offsets.data(), nullptr, device, out);
+    r = open_common(&p, graph.data(), nullptr, graph.size(), offsets.data(), nullptr, device, out);
+    if (r == 0) {
+        // a saved device index (bvg_save_index) that is not older than the graph is loaded instead of rebuilt (cf. the .obl cache, BVG:1545-1555);
+        // anything wrong with it just means the index is built as usual
+        struct stat sg {}, si {};
+        const std::string ip = base + ".bvgidx";
+        if (stat(ip.c_str(), &si) == 0 && stat((base + ".graph").c_str(), &sg) == 0 && si.st_mtime >= sg.st_mtime) (void)load_index_impl(*out, ip.c_str());
+    }
+    return r;
     });
 }
 
@@ -1679,6 +1806,8 @@ int bvg_shard_bounds(bvg_graph* g, int k, int balance, int64_t* bounds) { return
 int bvg_scan_shard(bvg_graph* g, int k, int r, int balance, bvg_scan_result* out, int64_t* from, int64_t* to) { return guarded([&] { return bvg_scan_shard_impl(g, k, r, balance, out, from, to); }); }
 int bvg_scan_multi(bvg_graph* const* per_gpu, int ngpu, int balance, bvg_scan_result* total, bvg_scan_result* per_shard) { return guarded([&] { return bvg_scan_multi_impl(per_gpu, ngpu, balance, total, per_shard); }); }
 int bvg_build_index(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, uint64_t* bytes) { return guarded([&] { return bvg_build_index_impl(g, from, to, entries, bytes); }); }
+int bvg_save_index(bvg_graph* g, const char* path) { return guarded([&] { return save_index_impl(g, path); }); }
+int bvg_load_index(bvg_graph* g, const char* path) { return guarded([&] { return load_index_impl(g, path); }); }
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ) { return guarded([&] { return bvg_successors_batch_impl(g, nodes, count, outdeg, succ, succ_cap, n_succ); }); }
 int bvg_tile(const bvg_graph* base, int64_t copies, bvg_graph** out) { return guarded([&] { return bvg_tile_impl(base, copies, out); }); }
 int bvg_mosaic(const bvg_graph* const* bases, int k, int64_t cycles, bvg_graph** out) { return guarded([&] { return bvg_mosaic_impl(bases, k, cycles, out); }); }
