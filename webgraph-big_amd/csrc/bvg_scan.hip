@@ -43,11 +43,33 @@ constexpr uint32_t kChunk = BVG_SCAN_CHUNK;    // leaf elements per lane and pas
 
 typedef uint32_t T;
 
+// Dealing flat tasks to lanes: every lane holds the inclusive prefix `incl` of its own task count; task t belongs to the first lane whose
+// prefix exceeds t.  Six shuffles find it (a binary search over the lanes) -- no map in LDS, no loop over a lane's tasks.  EVERY lane
+// must call it (a shuffle under a lane mask reads 0 from the masked lanes).
+__device__ __forceinline__ uint32_t task_owner(uint32_t incl, uint32_t t) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 32; step; step >>= 1) {
+        const uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), 64);
+        lo += v <= t ? step : 0u;
+    }
+    return lo < 64 ? lo : 63u;
+}
+// the k-th set bit of a 64-bit mask (k < popcount)
+__device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t step = 32; step; step >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(m & ((1ull << (pos + step)) - 1ull));     // set bits below pos + step (pos + step <= 63 here)
+        pos += c <= k ? step : 0u;
+    }
+    return pos;
+}
+
 __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
     __shared__ uint16_t nd_d[kRing];              // outdegree, clamped (a list longer than the pool fails the block before anything copies from it)
-    __shared__ uint32_t rtmap[128];               // task maps: residual segments -> lanes (two per lane), extras / positions / chunks -> lanes
 
     const unsigned lane = threadIdx.x;
     const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
@@ -372,25 +394,24 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 const uint32_t Tn = hasres ? ce + (shortt ? 0u : 1u) : 0u;            // long tasks of this node
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
                 const uint64_t smask = ballot(shortt);
-                const uint32_t ss = NL + (uint32_t)__popcll(smask & ((1ull << lane) - 1ull)), Ttot = NL + (uint32_t)__popcll(smask);
+                const uint32_t Ttot = NL + (uint32_t)__popcll(smask);
                 bool tbad = false;
                 // RU tasks per lane and pass, decoded in one interleaved loop: two independent chains per lane hide each other's LDS latency
                 auto task_passes = [&](auto RUc) {
                 constexpr uint32_t RU = decltype(RUc)::value, RP = 64u * RU;
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
-                    {
-                        const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
-                        const uint32_t q1 = ts >= p0 + RP ? 0u : (ts + Tn > p0 + RP ? p0 + RP - ts : Tn);
-                        for (uint32_t q = q0; q < q1; q++) rtmap[ts + q - p0] = lane | (q << 8);
-                        if (shortt && ss >= p0 && ss < p0 + RP) rtmap[ss - p0] = lane | (ce << 8);
-                    }
-                    wave_sync();
                     bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
 #pragma unroll
                     for (uint32_t u = 0; u < RU; u++) {
-                        tl[u] = p0 + 64u * u + lane < Ttot;
-                        const uint32_t ent = tl[u] ? rtmap[64u * u + lane] : lane;
-                        const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                        const uint32_t t = p0 + 64u * u + lane;
+                        tl[u] = t < Ttot;
+                        // long tasks [0, NL): segment t - (tasks of the lanes before) of the lane that owns it; short tails [NL, Ttot): the
+                        // last segment of the (t - NL)-th lane that has one
+                        const bool isl = t < NL;
+                        const uint32_t lown = task_owner(tincl, isl ? t : 0u), sown = select_bit(smask, (tl[u] && !isl) ? t - NL : 0u);
+                        const int nl = tl[u] ? (int)(isl ? lown : sown) : (int)lane;
+                        const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64), s_ce = (uint32_t)__shfl((int)ce, nl, 64);
+                        const uint32_t q = tl[u] ? (isl ? t - s_ts : s_ce) : 0u;
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
                         const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? rtb : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
@@ -440,7 +461,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                             if (on[u] && tn > tpend[u]) { tbad = true; cnt[u] = 0; }
                         }
                     }
-                    wave_sync();
                 }
                 };
                 if (Ttot > 96u) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
@@ -469,7 +489,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const uint32_t tq0 = BVG_T0();
 
             // ------------------------------------------------------------------ phase 2 of the sub-row
-            uint32_t* const tmap = rtmap + 64;
             constexpr uint32_t HS = 16;                                       // interval entry: length | position << HS
             const T HM = (T)0xFFFFu;
             uint32_t rlbN = 0, rlenS = rlenN;
@@ -529,15 +548,11 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     const uint32_t In = mem ? nresN + ic : 0u;
                     const uint32_t iincl2 = wave_incl_scan32(In), is = iincl2 - In, Itot = lane_get(iincl2, 63);
                     for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
-                        {
-                            const uint32_t q0 = is < p0 ? p0 - is : 0u;
-                            const uint32_t q1 = is >= p0 + 64u ? 0u : (is + In > p0 + 64u ? p0 + 64u - is : In);
-                            for (uint32_t q = q0; q < q1; q++) tmap[is + q - p0] = lane | (q << 8);
-                        }
-                        wave_sync();
                         const bool tl = p0 + lane < Itot;
-                        const uint32_t ent = tl ? tmap[lane] : lane;
-                        const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                        const uint32_t own = task_owner(iincl2, p0 + lane);       // (every lane takes part in the shuffles)
+                        const int nl = tl ? (int)own : (int)lane;
+                        const uint32_t s_first = (uint32_t)__shfl((int)is, nl, 64);
+                        const uint32_t q = tl ? p0 + lane - s_first : 0u;
                         const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenS, nl, 64);
                         const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                         const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
@@ -594,15 +609,11 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 BVG_T1(1, tq1);
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
                     const uint32_t tq2 = BVG_T0();
-                    {   // task map of this pass: (node lane, task index inside the node)
-                        const uint32_t q0 = ts < p0 ? p0 - ts : 0u;
-                        const uint32_t q1 = ts >= p0 + 64u ? 0u : (ts + Tn > p0 + 64u ? p0 + 64u - ts : Tn);
-                        for (uint32_t q = q0; q < q1; q++) tmap[ts + q - p0] = lane | (q << 8);
-                    }
-                    wave_sync();
-                    const bool tl = p0 + lane < Ttot;
-                    const uint32_t ent = tl ? tmap[lane] : lane;
-                    const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
+                    const bool tl = p0 + lane < Ttot;                     // task of this lane: (node lane, task index inside the node)
+                    const uint32_t own = task_owner(tincl, p0 + lane);           // (every lane takes part in the shuffles)
+                    const int nl = tl ? (int)own : (int)lane;
+                    const uint32_t s_first = (uint32_t)__shfl((int)ts, nl, 64);
+                    const uint32_t q = tl ? p0 + lane - s_first : 0u;
                     const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenS, nl, 64);
                     const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                     const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
@@ -671,15 +682,11 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 const uint32_t cincl = wave_incl_scan32(nch), cs = cincl - nch, Ctot = lane_get(cincl, 63);
                 const uint32_t e_k0 = __shfl(k0, (int)((e_hi >> 24) & 63u), 64), e_k1 = __shfl(k1, (int)((e_hi >> 24) & 63u), 64);
                 for (uint32_t p0 = 0; p0 < Ctot; p0 += 64) {
-                    {
-                        const uint32_t q0 = cs < p0 ? p0 - cs : 0u;
-                        const uint32_t q1 = cs >= p0 + 64u ? 0u : (cs + nch > p0 + 64u ? p0 + 64u - cs : nch);
-                        for (uint32_t q = q0; q < q1; q++) tmap[cs + q - p0] = lane | (q << 8);
-                    }
-                    wave_sync();
                     const bool tl = p0 + lane < Ctot;
-                    const uint32_t te = tl ? tmap[lane] : lane;
-                    const int sl = (int)(te & 63u); const uint32_t q = te >> 8;
+                    const uint32_t own = task_owner(cincl, p0 + lane);           // (every lane takes part in the shuffles)
+                    const int sl = tl ? (int)own : (int)lane;
+                    const uint32_t s_first = (uint32_t)__shfl((int)cs, sl, 64);
+                    const uint32_t q = tl ? p0 + lane - s_first : 0u;
                     const uint32_t c_lo = __shfl(e_lo, sl, 64), c_hi = __shfl(e_hi, sl, 64);
                     const uint32_t c_k0 = __shfl(e_k0, sl, 64), c_k1 = __shfl(e_k1, sl, 64);
                     const uint32_t c_len = c_hi & 0xFFFFFFu, o = q * kChunk;
@@ -742,7 +749,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
 }  // namespace
 
 // what the kernel needs of LDS besides the pool and the scratch area (static arrays)
-size_t scan_static_lds() { return (size_t)kRing * 4 + 128 * 4; }
+size_t scan_static_lds() { return (size_t)kRing * 4; }
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
