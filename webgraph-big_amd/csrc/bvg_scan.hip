@@ -38,7 +38,6 @@ using namespace rows;
 #define BVG_SCAN_CHUNK 8
 #endif
 constexpr uint32_t kNoList = 0xFFFFu;
-constexpr uint32_t kQueueMin = 48;             // run descriptors the scratch area always keeps room for
 constexpr uint32_t kChunk = BVG_SCAN_CHUNK;    // leaf elements per lane and pass (a kept copy block of a web graph is ~9 elements long)
 
 typedef uint32_t T;
@@ -54,6 +53,14 @@ __device__ __forceinline__ uint32_t task_owner(uint32_t incl, uint32_t t) {
         lo += v <= t ? step : 0u;
     }
     return lo < 64 ? lo : 63u;
+}
+// gamma from the LDS window: codes of up to 31 bits (values below 2^15: every copy block and interval of a list that fits LDS) from one
+// 32-bit window; the 64-bit decoder only where a lane needs it.  Returns the length, 0 = does not fit.
+__device__ __forceinline__ uint32_t gamma_at(const uint32_t* stage, uint32_t rel, uint64_t& v) {
+    const uint32_t w = win32<LIN>(stage, rel);
+    const uint32_t lz = w ? (uint32_t)__builtin_clz(w) : 32u;
+    if (lz < 16) { const uint32_t len = 2 * lz + 1; v = (w >> (32u - len)) - 1u; return len; }
+    return gamma64(win64<LIN>(stage, rel), v);
 }
 // the k-th set bit of a 64-bit mask (k < popcount)
 __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
@@ -218,8 +225,8 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 bad |= l == 0 || v > pend - rel + 1; rel += l; bc = bad ? 0u : (uint32_t)v;
             }
         }
-        // the copy blocks and intervals of the super-row go to the scratch area, which must keep kQueueMin run descriptors free
-        const uint32_t SCRH = SCR > 2u * kQueueMin ? SCR - 2u * kQueueMin : 0u;
+        // the copy blocks and intervals of the super-row go to the scratch area
+        const uint32_t SCRH = SCR;
         const uint32_t bincl = wave_incl_scan32(bc > SCRH ? SCRH + 1 : bc);
         { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCRH)); K1 = kb < K1 ? kb : K1; }
         if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }       // one node's copy blocks exceed the scratch area
@@ -231,18 +238,19 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             if (ref > 0) {
                 int64_t copied = 0, tot = 0;
                 for (uint32_t i = 0; i < bc; i++) {
-                    const uint32_t lb = gamma64(win64<LIN>(stage, rel), v);
+                    const uint32_t lb = gamma_at(stage, rel, v);
                     if (lb == 0 || rel > pend) { bad = true; bc = i; break; }
                     rel += lb;
                     const uint32_t b = (uint32_t)v + (i ? 1u : 0u);
-                    scr[sb + i] = (T)b;
                     tot += b;
                     if (!(i & 1)) copied += b;
+                    // straight in PREFIX form (MaskPrefix): end position of block i in the referenced list | elements kept up to and including it
+                    scr[sb + i] = MaskPrefix<T>::pack((uint32_t)tot, (uint32_t)copied);
                 }
                 rlenN = nd_d[(uint32_t)(x - ref) & RM];
                 if (!(bc & 1)) copied += (int64_t)rlenN - tot;                // BVG:1030
                 extra = (int64_t)d - copied;
-                if (tot > (int64_t)rlenN || extra < 0 || copied < 0) bad = true;   // (cannot happen in a validated block)
+                if (tot > (int64_t)rlenN || tot > 0xFFFF || extra < 0 || copied < 0) bad = true;   // (cannot happen in a validated block)
             }
             if (extra > 0 && minint != 0) {                                   // always gamma
                 const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
@@ -259,8 +267,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         }
         if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }       // one node's intervals exceed the scratch area
         ib = btot + iincl - iw;
-        const uint32_t qb = (btot + lane_get(iincl, K1 - 1) + 1u) & ~1u;      // the run queue follows the blocks and intervals (8-byte entries)
-        const uint32_t qcap = (SCR - qb) >> 1;
         parse = parse && lane < K1;
         // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals
         if (parse) {
@@ -268,8 +274,8 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 int64_t prev = 0;
                 for (uint32_t i = 0; i < ic; i++) {
                     uint64_t v1, v2;
-                    const uint32_t l1 = gamma64(win64<LIN>(stage, rel), v1);
-                    const uint32_t l2 = gamma64(win64<LIN>(stage, rel + l1), v2);
+                    const uint32_t l1 = gamma_at(stage, rel, v1);
+                    const uint32_t l2 = gamma_at(stage, rel + l1, v2);
                     if (l1 == 0 || l2 == 0 || rel > pend) { bad = true; ic = i; break; }
                     rel += l1 + l2;
                     const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
@@ -345,8 +351,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             sk_run += lane_get(eincl, 63);
         }
         if (sk_run > sk_n) { failed = true; fail_need = 0xFFFFFFF5u; break; }   // index out of step with the stream
-        const uint32_t nqn = (on1 && !stored && repn && d > 0) ? (ref > 0 ? ((bc + 2u) >> 1) : 0u) + ic : 0u;   // run descriptors of a leaf: kept copy blocks
-                                                                                 // (the explicit ones at even indices + the implicit tail when their number is even, MaskedLongIterator.java:73-78) and intervals
         BVG_T1(8, tq8);
         BVG_T1(5, tq5);
 
@@ -359,11 +363,10 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const bool cand = on1 && lane >= sa;
             const uint32_t size = (cand && stored) ? dclamp : 0u;
             const uint32_t rsz = (cand && stored) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
-            const uint32_t nq = lane >= sa ? nqn : 0u;
-            const uint32_t sincl = wave_incl_scan32(size), rincl = wave_incl_scan32(rsz), qincl = wave_incl_scan32(nq);
-            const bool fits = lane >= sa && lane < K1 && (uint64_t)sincl + rincl <= avail && qincl <= qcap;
+            const uint32_t sincl = wave_incl_scan32(size), rincl = wave_incl_scan32(rsz);
+            const bool fits = lane >= sa && lane < K1 && (uint64_t)sincl + rincl <= avail;
             const uint32_t se = sa + (uint32_t)__popcll(ballot(fits));          // (the sums are prefixes: `fits` is a contiguous run from sa)
-            if (se == sa) {                                                   // the first node alone overflows the pool (or the queue)
+            if (se == sa) {                                                   // the first node alone overflows the pool
                 failed = true;
                 uint32_t d0 = lane_get(d, sa); const uint32_t n0 = lane_get(nres, sa);
                 if (d0 <= 0x3FFFFFFFu) d0 += (n0 > d0 ? d0 : n0) + 1u;
@@ -375,7 +378,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const bool rep = act && repn;
             const uint32_t base = pool_used + (sincl - size);
             const uint32_t rtb = CAP - (rincl > CAP ? CAP : rincl);
-            const uint32_t qs = qincl - nq, Q = lane_get(qincl, se - 1);
             if (act) nd_base[(uint32_t)x & RM] = (uint16_t)(stored ? base : kNoList);        // (a leaf has no list: nothing to compact, nothing to copy from)
             pool_used += lane_get(sincl, se - 1);
             BVG_T1(8, tq8b);
@@ -500,30 +502,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             if (pure) { rlbN = rtb; rlenS = nres; }
             const uint32_t rtbN = pure ? rtb + nres : rtb, nresN = pure ? 0u : nres;
             const bool emitn = act && d > 0;
-            // ---- run descriptors of the leaves {lo = first pool element of the run | first value of the interval, hi = length | node lane
-            //      << 24 | interval << 31}; copy blocks of the stored nodes -> prefix form (MaskPrefix)
-            {
-                uint64_t* const queue = reinterpret_cast<uint64_t*>(scr + qb);
-                const bool leaf = emitn && !stored && rep;
-                if (emitn && ref > 0 && (stored || leaf)) {
-                    uint32_t pp = 0, kk = 0, slot = qs;
-                    const uint32_t tag = (uint32_t)lane << 24;
-                    for (uint32_t i = 0; i < bc; i++) {
-                        const uint32_t b = (uint32_t)scr[sb + i];
-                        if (stored) { pp += b; if (!(i & 1u)) kk += b; scr[sb + i] = MaskPrefix<T>::pack(pp, kk); }
-                        else {
-                            if (!(i & 1u)) { queue[slot] = (uint64_t)(rlbN + pp) | ((uint64_t)(b | tag) << 32); slot++; }
-                            pp += b;
-                        }
-                    }
-                    if (!stored && !(bc & 1u)) { queue[slot] = (uint64_t)(rlbN + pp) | ((uint64_t)((rlenS - pp) | tag) << 32); slot++; }
-                }
-                if (leaf && ic) {
-                    uint32_t slot = qs + (ref > 0 ? ((bc + 2u) >> 1) : 0u);
-                    const uint32_t tag = ((uint32_t)lane << 24) | 0x80000000u;
-                    for (uint32_t i = 0; i < ic; i++) { queue[slot] = (uint64_t)scr[ib + 2 * i] | ((uint64_t)((uint32_t)scr[ib + 2 * i + 1] | tag) << 32); slot++; }
-                }
-            }
             // ---- level-synchronous emission by POSITION of the stored lists (as in bvg_rows.hip; no overlap checks: validated)
             const bool inrow = act && ref > 0 && ref + sa <= lane;                // the referenced list belongs to this sub-row
             uint32_t lvl = 0;
@@ -672,11 +650,32 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             // ---------------- leaf pass: the run queue, cut into chunks of kChunk elements dealt to all lanes.  Every referenced list
             // is complete by now.  A chunk is straight-line work: 4 elements per step, their LDS reads issued together.
             const uint32_t tqL = BVG_T0();
+            // a leaf's items: its kept copy blocks -- block 2j of the copy mask, and the implicit tail behind an even number of blocks
+            // (MaskedLongIterator.java:73-78): runs [start, end) of the referenced list -- and its intervals
+            const bool leaf = emitn && !stored && rep;
+            const uint32_t nkept = (leaf && ref > 0) ? ((bc + 2u) >> 1) : 0u;
+            const uint32_t Ln = leaf ? nkept + ic : 0u;
+            const uint32_t lincl = wave_incl_scan32(Ln), lfirst = lincl - Ln, Q = lane_get(lincl, 63);
             for (uint32_t d0 = 0; d0 < Q; d0 += 64) {
-                const uint64_t* const queue = reinterpret_cast<const uint64_t*>(scr + qb);
                 const bool dl = d0 + lane < Q;
-                const uint64_t ent = dl ? queue[d0 + lane] : 0ull;
-                const uint32_t e_lo = (uint32_t)ent, e_hi = (uint32_t)(ent >> 32);
+                const uint32_t iown = task_owner(lincl, d0 + lane);
+                const int il = dl ? (int)iown : (int)lane;
+                const uint32_t i_first = (uint32_t)__shfl((int)lfirst, il, 64), i_nk = (uint32_t)__shfl((int)nkept, il, 64), i_bc = (uint32_t)__shfl((int)bc, il, 64);
+                const uint32_t i_sb = (uint32_t)__shfl((int)sb, il, 64), i_ib = (uint32_t)__shfl((int)ib, il, 64);
+                const uint32_t i_rlb = (uint32_t)__shfl((int)rlbN, il, 64), i_rlen = (uint32_t)__shfl((int)rlenS, il, 64);
+                uint32_t e_lo = 0, e_hi = 0;
+                if (dl) {
+                    const uint32_t j = d0 + lane - i_first;
+                    if (j < i_nk) {
+                        const uint32_t bi = 2u * j;
+                        const uint32_t st0 = bi ? MaskPrefix<T>::pos(scr[i_sb + bi - 1u]) : 0u;
+                        const uint32_t en0 = bi < i_bc ? MaskPrefix<T>::pos(scr[i_sb + bi]) : i_rlen;
+                        e_lo = i_rlb + st0; e_hi = (en0 > st0 ? en0 - st0 : 0u) | ((uint32_t)il << 24);
+                    } else {
+                        const uint32_t k = j - i_nk;
+                        e_lo = (uint32_t)scr[i_ib + 2u * k]; e_hi = (uint32_t)scr[i_ib + 2u * k + 1u] | ((uint32_t)il << 24) | 0x80000000u;
+                    }
+                }
                 const uint32_t e_len = e_hi & 0xFFFFFFu;
                 const uint32_t nch = (e_len + kChunk - 1u) / kChunk;
                 const uint32_t cincl = wave_incl_scan32(nch), cs = cincl - nch, Ctot = lane_get(cincl, 63);
