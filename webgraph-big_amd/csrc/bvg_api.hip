@@ -614,10 +614,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // queue) + static arrays.  Resident wavefronts per CU step down with it; take the largest even count whose pool
                 // still holds a row's worth of lists (leaves take no pool: about half the row kernel's need).
                 const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 384);   // a super-row: the records that fit it, up to 64 (profiles/r03_ab_cfg.txt)
-                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 512;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
+                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 448;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
                 const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64 + (uint64_t)stagew * 4 + scrw * 4;
                 auto foot = [&](uint64_t pe) { return (pe * 4 + fixed + 127) & ~127ull; };
-                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 18.0;   // window lists + a sub-row's stored lists and parked residuals
+                const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 20.0;   // window lists + a sub-row's stored lists and parked residuals
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
                 for (uint64_t w : {16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
