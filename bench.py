@@ -230,8 +230,10 @@ def main():
     if dist is not None:
         elapsed = S.allreduce_max(elapsed, device=cuda)
         k_ms = S.allreduce_max(float(np.mean(kernel_ms)), device=cuda)
+        idx_all, lean_all = S.allreduce_scan(int(r["index_entries"]), int(r["lean_blocks"]), device=cuda)   # what every rank scanned with (untimed bookkeeping)
     else:
         k_ms = float(np.mean(kernel_ms))
+        idx_all, lean_all = int(r["index_entries"]), int(r["lean_blocks"])
 
     if rank == 0:
         edges_per_s = tot_arcs * args.steps / elapsed
@@ -257,6 +259,7 @@ def main():
                                    + ", rows_kernel / giant_kernel / decode_kernel<slow> for the other blocks and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": gbytes, "index_bytes_per_launch": r["index_bytes"]},
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
+            "index": {"skip_entries_rank0": int(r["index_entries"]), "skip_entries_all_ranks": idx_all, "lean_blocks_rank0": int(r["lean_blocks"]), "lean_blocks_all_ranks": lean_all},
             "index_build_s": max(first_scan_s - steady_s, 0.0), "hbm_resident_bytes": int(resident),
             "host": {"generate_s": gen_s, "upload_s": upload_s, "tile_s": tile_s, "first_scan_s": first_scan_s},
         }

@@ -1,22 +1,28 @@
 // bvg_scan.hip — the lean scan kernel: tier 0 (and the big-LDS classes) of a steady-state successor scan.
 //
-// Same decomposition as the row kernel of bvg_rows.hip — one wavefront per node block, rows of up to 64 consecutive nodes with one
-// node per lane, the stream window / the lists of the window / the row's copy blocks and intervals all in LDS — but specialised for
-// what a scan of an already VALIDATED block needs (bvg_api.hip build_skip: the index-building pass of the row kernel has decoded the
-// block from end to end with every consistency check on, and the stream in HBM is immutable afterwards):
+// One wavefront per node block, everything a record touches in LDS, like the row kernel of bvg_rows.hip -- but specialised for what a
+// scan of an already VALIDATED block needs (bvg_api.hip build_skip: the index-building pass of the row kernel has decoded the block
+// from end to end with every consistency check on, and the stream in HBM is immutable afterwards):
 //   * 32-bit successors, BVGraph's default codings (gamma / unary / zeta_k), scan mode only, residual skip index present;
+//   * SUPER-ROWS and SUB-ROWS.  Up to 64 consecutive records (what fits the stream window) are parsed at once, one per lane: outdegree,
+//     reference, copy blocks (straight into prefix form), intervals -- the lock-step part of the work, done with every lane busy.  All
+//     references of the super-row are then known (and those of the next one's first W records are peeked at), so exactly the lists
+//     that some later node copies from are STORED; every other node is a LEAF.  The lists are built in sub-rows of as many nodes as the
+//     pool holds next to the stored lists of the W nodes before them -- so the LDS footprint follows the pool, not the 64-record
+//     parse, and 14 wavefronts fit a CU where the row kernel holds 8;
 //   * the three streams of a record are disjoint (BVG:1062-1090 merges them; a stream where they overlap failed validation and stays
-//     on the checking kernels), so nothing has to be located to be COUNTED: every residual is folded into the checksum the moment
-//     it is decoded, and a list that no later node copies from ("leaf": ~60 % of the nodes of a web graph) is never materialised,
-//     never positioned and its residuals are never parked in LDS;
-//   * what a leaf still owes the checksum — the kept elements of the list it references (MaskedLongIterator.java:73-100) and its
-//     interval elements (LongIntervalSequenceIterator.java:57-78) — is described by RUNS: a kept copy block is a contiguous run of the
-//     referenced list in LDS, an interval is an iota.  The lanes write one 8-byte descriptor per run into a queue, the queue is cut
-//     into chunks of kChunk elements and dealt to all 64 lanes, and a chunk is four straight-line groups of {4 LDS reads in flight,
-//     4 mixes}: no per-element block bookkeeping, no branch inside a chunk;
-//   * lists that ARE copied from are built exactly as in the row kernel (emission by output position, level by level).
-// LDS per wavefront is what bounds the resident wavefronts and those bound the rate (profiles/r02_occupancy_ldspad.txt): without the
-// parked residuals and lists of the leaves a row needs about half the pool of the row kernel.
+//     on the checking kernels), so nothing has to be located to be COUNTED: every residual is folded into the checksum the moment it is
+//     decoded, and a leaf (~60 % of the nodes of a web graph) is never materialised, never positioned, its residuals never parked;
+//   * what a leaf still owes the checksum -- the kept elements of the list it references (MaskedLongIterator.java:73-100) and its
+//     interval elements (LongIntervalSequenceIterator.java:57-78) -- are RUNS: a kept copy block is a contiguous run of the referenced
+//     list in LDS (read off the prefix form of the blocks), an interval is an iota.  The runs of a sub-row are cut into chunks of kChunk
+//     elements dealt to all 64 lanes; a chunk is straight-line groups of {4 LDS reads in flight, 4 mixes}: no per-element block
+//     bookkeeping, no branch inside a chunk;
+//   * stored lists are built as in the row kernel (emission by output position, level by level);
+//   * flat tasks (residual segments, extras, position tasks, chunks) are dealt to lanes by a binary search over the prefix sums of the
+//     task counts with six shuffles (task_owner) -- no task maps in LDS, no loop over a lane's tasks.
+// At 14 wavefronts per CU the kernel is bound by vector-instruction issue (profiles/r03_pmc_*): hiding more latency (prefetching the
+// next window or the skip entries into registers, more wavefronts) no longer moves it; fewer instructions per arc do.
 //
 // A block that does not fit (pool, window, scratch) fails over to the row kernel's tiers like any other; a block without the
 // validation mark never gets here (the host sorts on it).
