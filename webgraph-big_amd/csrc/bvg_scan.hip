@@ -68,6 +68,19 @@ __device__ __forceinline__ uint32_t gamma_at(const uint32_t* stage, uint32_t rel
     if (lz < 16) { const uint32_t len = 2 * lz + 1; v = (w >> (32u - len)) - 1u; return len; }
     return gamma64(win64<LIN>(stage, rel), v);
 }
+// zeta_3 (BVGraph's default residual code) from a 32-bit window, straight-line and without the two integer multiplies of the general
+// form (quarter rate): codes of up to 31 bits (h <= 6: values below 2^21 - 1); returns the length, 0 = take the 64-bit decoder
+__device__ __forceinline__ uint32_t zeta3_fast32(uint32_t w, uint32_t& val) {
+    const uint32_t h = w ? (uint32_t)__builtin_clz(w) : 32u;
+    const uint32_t fits = h <= 6u ? 1u : 0u, hh = fits ? h : 0u;                 // h = 7 is 32 bits with the extra bit
+    const uint32_t h3 = hh + (hh << 1), nb = h3 + 2u, zt = (hh << 2) + 3u;       // payload bits, code length without the extra bit
+    const uint32_t t = (w << (hh + 1u)) >> (32u - nb);
+    const uint32_t left = 1u << h3;
+    const bool shortc = t < left;
+    const uint32_t ext = ((t << 1) | ((w >> (31u - zt)) & 1u)) - 1u;
+    val = shortc ? t + left - 1u : ext;
+    return fits ? zt + (shortc ? 0u : 1u) : 0u;
+}
 // the k-th set bit of a 64-bit mask (k < popcount)
 __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
     uint32_t pos = 0;
@@ -79,6 +92,8 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
     return pos;
 }
 
+// NBZ: the node base is 0 (no carry handling in the checksum key); Z3: zeta_3 residuals (the specialised decoder)
+template <bool NBZ, bool Z3>
 __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
@@ -103,7 +118,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
     const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
-    const bool nbz = a.node_base == 0;
+    constexpr bool nbz = NBZ;
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
     wave_sync();
@@ -447,7 +462,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                         for (uint32_t u = 0; u < RU; u++) w32[u] = win32<LIN>(stage, trel[u]);   // all chains' LDS reads first: they overlap
 #pragma unroll
                         for (uint32_t u = 0; u < RU; u++) {
-                            uint32_t v32 = 0; len[u] = zfast ? zeta_fast32(w32[u], zk, v32) : 0u; val[u] = v32;
+                            uint32_t v32 = 0; len[u] = Z3 ? zeta3_fast32(w32[u], v32) : (zfast ? zeta_fast32(w32[u], zk, v32) : 0u); val[u] = v32;
                             slow |= on[u] && len[u] == 0;
                         }
                         if (ballot(slow)) {                                   // codes longer than 31 bits (or zeta_1): one rare, wave-uniform detour
@@ -760,7 +775,9 @@ void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s) {
     if (nblocks == 0) return;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
-    hipLaunchKernelGGL(scan_kernel, dim3(nblocks), dim3(64), dyn, s, a);
+    const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
+    if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
 
 }  // namespace bvg
