@@ -435,7 +435,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     // chains (several short levels per row) are served better by the pipelined node-per-lane loop alone.
     {
         const double avg_d = sh->p.arcs > 0 && sh->p.nodes > 0 ? (double)sh->p.arcs / (double)sh->p.nodes : 16.0;
-        a.emit_tasks = (sh->p.window_size == 0 || avg_d >= 24.0) ? 1u : 0u;
+        a.emit_tasks = (sh->p.window_size == 0 || avg_d >= 8.0) ? 1u : 0u;     // (sparse web shape, 11 arcs a node: the scan kernel still gains 3 %, profiles/r03_web_lean.txt)
         if (knob("BVG_EMIT")) a.emit_tasks = (uint32_t)strtoul(knob("BVG_EMIT"), nullptr, 10) ? 1u : 0u;
         a.pass_cost = knob("BVG_PASSCOST") ? (uint32_t)strtoul(knob("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
@@ -613,7 +613,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
                 // queue) + static arrays.  Resident wavefronts per CU step down with it; take the largest even count whose pool
                 // still holds a row's worth of lists (leaves take no pool: about half the row kernel's need).
-                const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 384);   // a super-row: the records that fit it, up to 64 (profiles/r03_ab_cfg.txt)
+                const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 512);   // a super-row: the records that fit it, up to 64 (profiles/r03_ab_cfg.txt, r03_ab_stage.txt)
                 const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 448;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
                 const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64 + (uint64_t)stagew * 4 + scrw * 4;
                 auto foot = [&](uint64_t pe) { return (pe * 4 + fixed + 127) & ~127ull; };
@@ -855,16 +855,27 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     { std::vector<uint32_t> none; r = run_global_tier(false, none); if (r) return r; }
     if (d_work) (void)hipFree(d_work);
 
-    unsigned long long acc[24];
+    unsigned long long acc[28];
     launch_reduce_acc(g->d_acc, kAccStripes, g->stream);
     HIPCHK(hipMemcpyAsync(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: position steps %llu, position passes %llu, extras passes %llu, rows %llu, position tasks %llu, leaf steps %llu, leaf passes %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[22], acc[23]);
     if ((a.dbg & 64u) && lean_blocks) fprintf(stderr, "[bvg] scan kernel rows: %llu super-rows, %llu sub-rows, %llu nodes in them\n", acc[5], acc[6], acc[7]);
+#ifndef BVG_PROF_WORK
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
         fprintf(stderr, "[bvg] phase 1 split (M): row set-up %.0f, headers %.0f, pool sizing %.0f, residuals %.0f; leaf pass %.0f (loop %.0f)\n", acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6, acc[20] / 1e6, acc[21] / 1e6);
     }
+#endif
+#ifndef BVG_PROF_WORK
+    if ((a.dbg & 64u) && acc[14])
+        fprintf(stderr, "[bvg] scan kernel, more wave-cycles (M): compaction %.0f, window staging %.0f, residual task set-up %.0f, stored-list marking %.0f\n", acc[24] / 1e6, acc[25] / 1e6, acc[26] / 1e6, acc[27] / 1e6);
+#else
+    if ((a.dbg & 64u) && (acc[24] | acc[25] | acc[26] | acc[27]))   // only the -DBVG_PROF -DBVG_PROF_WORK build (`make work`): the slots above hold counts, not cycles
+        fprintf(stderr, "[bvg] scan kernel work: levels %llu | Z1 passes %llu tasks %llu | Z2 passes %llu tasks %llu steps %llu positions %llu | residual task passes %llu steps %llu residuals %llu, "
+                "lane-per-node steps %llu residuals %llu | leaf item passes %llu chunk passes %llu steps(x4) %llu elements %llu\n",
+                acc[9], acc[12], acc[25], acc[10], acc[11], acc[13], acc[14], acc[15], acc[16], acc[17], acc[18], acc[26], acc[27], acc[20], acc[21], acc[24]);
+#endif
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];
         res->kernel_ms = kernel_ms; res->launches = launches; res->slow_blocks = slow_blocks; res->lean_blocks = lean_blocks;

@@ -132,13 +132,33 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     uint32_t cnt_super = 0, cnt_sub = 0, cnt_nodes = 0;      // BVG_DBG & 64: work counters (wave-uniform)
     // -DBVG_PROF builds only (`make prof`): wave-cycles per section, reported with BVG_DBG & 64 through the row kernel's counters
     // {0 descriptors + levels, 1 Z2 sizing, 2 Z2 set-up, 3 Z1, 4 Z2 loop, 5 phase 1, 6 row set-up, 7 headers, 8 pool sizing, 9 residuals, 10 leaf pass, 11 leaf loop}
-#ifdef BVG_PROF
-    uint32_t cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+    // `make work`: the same slots count WORK instead of cycles (wave-uniform counts; lane sums go through BVG_WCL):
+    // {0 levels with members, 1 Z2 passes, 2 Z2 tasks, 3 Z1 passes, 4 Z2 loop steps, 5 Z2 positions, 6 residual task passes, 7 residual task-loop steps,
+    //  8 residuals decoded by tasks, 9 steps of the lane-per-node residual loop, 10 leaf chunk passes, 11 leaf loop steps (4 elements each),
+    //  12 leaf elements, 13 Z1 tasks, 14 residuals of the lane-per-node loop, 15 leaf item passes}
+    uint32_t cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define BVG_T0() 0u
+#define BVG_T1(i, t) do { (void)(t); } while (0)
+#define BVG_WC(i, n) do { cyc[i] += (uint32_t)(n); } while (0)
+#define BVG_WCL(i, n) do { cyc[i] += wave_sum32((uint32_t)(n)); } while (0)
+#elif defined(BVG_MARKS)
+    // `hipcc -S -DBVG_MARKS`: the section boundaries as comments in the assembly (static instruction counts per section)
+#define BVG_T0() ([]() { asm volatile("; BVGMARK begin"); return 0u; }())
+#define BVG_T1(i, t) do { (void)(t); asm volatile("; BVGMARK end %0" :: "n"(i)); } while (0)
+#define BVG_WC(i, n) do { } while (0)
+#define BVG_WCL(i, n) do { } while (0)
+#elif defined(BVG_PROF)
+    uint32_t cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BVG_T0() ((uint32_t)clock64())
 #define BVG_T1(i, t) do { cyc[i] += (uint32_t)clock64() - (t); } while (0)
+#define BVG_WC(i, n) do { } while (0)
+#define BVG_WCL(i, n) do { } while (0)
 #else
 #define BVG_T0() 0u
 #define BVG_T1(i, t) do { (void)(t); } while (0)
+#define BVG_WC(i, n) do { } while (0)
+#define BVG_WCL(i, n) do { } while (0)
 #endif
 
     // residual skip index: entries of this block
@@ -161,6 +181,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         if (livelane && my_base != kNoList) nd_base[(uint32_t)y & RM] = (uint16_t)nbase;
         pool_used = lane_get(nincl, 63);
         wave_sync();
+        BVG_WC(5, pool_used);                                             // (work-count build: elements carried over, per compaction: slot 3 below counts them)
     };
 
     int64_t r0 = hs;
@@ -177,7 +198,8 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         const uint32_t hbit = x < s ? (uint32_t)(s - 1 - x) : 0;
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
         const uint32_t left = (uint32_t)(e - r0 > 64 ? 64 : e - r0);
-        if (pool_used > 0) compact(r0);
+        { const uint32_t tqc = BVG_T0(); if (pool_used > 0) compact(r0); BVG_T1(12, tqc); }
+        const uint32_t tqs = BVG_T0();
         {   // (re)stage the window when this super-row's records are not covered by it
             const uint64_t row_lo = lane_get64(off_x, 0);
             const uint64_t row_hi = lane_get64(rec_end, left - 1);
@@ -195,6 +217,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 wave_sync();
             }
         }
+        BVG_T1(13, tqs);
         // the super-row is cut where the records stop fitting the window (the next one restages from there)
         const bool inwin = in_range && rec_end + 96 <= stg_bit0 + stg_bits && off_x >= stg_bit0;
         uint32_t K1;
@@ -318,6 +341,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         //      super-row is known now) or one of its last W nodes, which the next super-row may reference.  Every other node is a leaf:
         //      no list, no parked residuals, only run descriptors.
         const bool on1 = needed && lane < K1;
+        const uint32_t tqp = BVG_T0();
         uint64_t refmask = 0;
         for (uint32_t r = 1; r <= W && r < 64; r++) refmask |= ballot(parse && ref == r) >> r;
         if (K1 != K1win) {
@@ -352,6 +376,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             if (ballot(unknown)) refmask |= K1 >= W ? (~0ull << (K1 - W)) : ~0ull;
             for (uint32_t j = 0; j < W && j < 64; j++) { const uint32_t t = lane_get(tgt, j); if (t < 64) refmask |= 1ull << t; }
         }
+        BVG_T1(15, tqp);
         const bool stored = (refmask >> lane) & 1ull;
         const bool repn = on1 && x >= rep_lo && x < rep_hi;
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
@@ -406,6 +431,9 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             // ---- D2: residuals (ResidualLongIterator, BVG:902-935): summed, and parked for the lists that are stored
             const bool rparse = parse && act;
             uint64_t csum = 0;
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+            if (!(sk_n != 0 && ballot(rparse && cntE != 0))) { BVG_WC(9, wave_max32(rparse ? nres : 0u)); BVG_WCL(14, rparse ? nres : 0u); }
+#endif
             if (sk_n != 0 && ballot(rparse && cntE != 0)) {
                 // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task.  Long tasks first
                 // (full segments and tails of more than kShortTask gaps), the short tails after them: a pass of 64 tasks lasts as long
@@ -423,6 +451,8 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 auto task_passes = [&](auto RUc) {
                 constexpr uint32_t RU = decltype(RUc)::value, RP = 64u * RU;
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
+                    BVG_WC(6, 1);
+                    const uint32_t tq9p = BVG_T0();
                     bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
 #pragma unroll
                     for (uint32_t u = 0; u < RU; u++) {
@@ -451,11 +481,21 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                             if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
                         }
                     }
+                    BVG_T1(14, tq9p);
                     for (uint32_t i = 0;; i++) {
+#ifdef BVG_ABLATE_RESLOOP
+                        break;
+#endif
                         bool on[RU]; bool any = false;
 #pragma unroll
                         for (uint32_t u = 0; u < RU; u++) { on[u] = i < cnt[u]; any |= on[u]; }
                         if (!ballot(any)) break;
+                        BVG_WC(7, 1);
+#ifdef BVG_EXP_DUMMY
+                        { uint32_t dm = i; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
+#endif
+#pragma unroll
+                        for (uint32_t u = 0; u < RU; u++) BVG_WCL(8, on[u] ? 1u : 0u);
                         uint32_t len[RU]; uint64_t val[RU]; bool slow = false;
                         uint32_t w32[RU];
 #pragma unroll
@@ -541,13 +581,18 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 const bool mem = emits && lvl == L;
                 remaining &= ~ballot(mem);
                 if (!ballot(mem)) continue;
+                BVG_WC(0, 1);
                 // ---------------- Z1: one lane per extra: its output position = (extras below it) + (copied elements below it)
                 const uint32_t tq3 = BVG_T0();
                 {
                     const uint32_t In = mem ? nresN + ic : 0u;
                     const uint32_t iincl2 = wave_incl_scan32(In), is = iincl2 - In, Itot = lane_get(iincl2, 63);
+#ifdef BVG_ABLATE_Z1
+                    if (false)
+#endif
                     for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
                         const bool tl = p0 + lane < Itot;
+                        BVG_WC(3, 1); BVG_WCL(13, tl ? 1u : 0u);
                         const uint32_t own = task_owner(iincl2, p0 + lane);       // (every lane takes part in the shuffles)
                         const int nl = tl ? (int)own : (int)lane;
                         const uint32_t s_first = (uint32_t)__shfl((int)is, nl, 64);
@@ -606,9 +651,13 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 }
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
                 BVG_T1(1, tq1);
+#ifdef BVG_ABLATE_Z2
+                if (false)
+#endif
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
                     const uint32_t tq2 = BVG_T0();
                     const bool tl = p0 + lane < Ttot;                     // task of this lane: (node lane, task index inside the node)
+                    BVG_WC(1, 1); BVG_WCL(2, tl ? 1u : 0u);
                     const uint32_t own = task_owner(tincl, p0 + lane);           // (every lane takes part in the shuffles)
                     const int nl = tl ? (int)own : (int)lane;
                     const uint32_t s_first = (uint32_t)__shfl((int)ts, nl, 64);
@@ -636,32 +685,46 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     }
                     const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
                     uint64_t zsum = 0;
+                    // BVG_WCL(5, pstop - p);
                     BVG_T1(2, tq2);
                     const uint32_t tq4 = BVG_T0();
+                    // One output position per step and lane.  With some fifty lanes at work nearly every step sees a lane at the end of a
+                    // copy block and another at a residual, so those two are handled without branches (the next block's entries and the
+                    // next residual position are read in every step, and selected); only the end of an interval -- rarer -- is a branch.
+                    const T* const blkp = scr + t_sb;
                     for (;;) {
+#ifdef BVG_ABLATE_Z2LOOP
+                        break;
+#endif
                         const bool todo = p < pstop;
                         if (!ballot(todo)) break;
-                        if (todo) {
-                            if (p == rnext) { ri++; rnext = (uint32_t)rt[ri]; }           // a residual: placed by Z1 (and summed when it was decoded)
-                            else {
-                                const uint32_t io = p - ivpos;
-                                const bool ii = io < ivlen;                               // LongIntervalSequenceIterator.java:71-78
-                                const T cv = rl[qcur < rlast ? qcur : rlast];
-                                const T vv = ii ? (T)(ivleft + (T)io) : cv;
-                                out[p] = vv;
-                                zsum += mix_node<T>(t_k0, t_k1, vv, nb_lo, nbz);
-                                if (ii) {
-                                    if (io + 1u == ivlen) {
-                                        ivk++; ivpos = kInf; ivlen = 0;
-                                        if (ivk < t_ic) { const T pk = scr[t_ib + 2 * ivk + 1]; ivlen = (uint32_t)(pk & HM); ivpos = (uint32_t)(pk >> HS); ivleft = scr[t_ib + 2 * ivk]; }
-                                    }
-                                } else {
-                                    qcur++;
-                                    if (--krem == 0) MaskPrefix<T>::next_block(scr + t_sb, t_bc, t_rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
-                                }
-                            }
-                            p++;
+                        BVG_WC(4, 1);
+#ifdef BVG_EXP_DUMMY
+                        { uint32_t dm = p; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
+#endif
+                        const T cv = rl[qcur < rlast ? qcur : rlast];
+                        const T e0 = blkp[bi], e1 = blkp[bi + 1u];                        // (reads past the node's blocks stay inside the scratch area / the window)
+                        const bool isr = p == rnext;                                      // a residual: placed by Z1 (and summed when it was decoded)
+                        const uint32_t io = p - ivpos;
+                        const bool ii = io < ivlen;                                       // LongIntervalSequenceIterator.java:71-78
+                        const bool emit = todo && !isr;
+                        const T vv = ii ? (T)(ivleft + (T)io) : cv;
+                        if (emit) out[p] = vv;
+                        zsum += mix_node<T>(t_k0, emit ? t_k1 : 0u, vv, nb_lo, nbz);
+                        const bool cp = emit && !ii;                                      // a copied element: MaskedLongIterator.java:81-100
+                        qcur += cp ? 1u : 0u; krem -= cp ? 1u : 0u;
+                        const bool cross = cp && krem == 0;                               // the keep block ended: skip block bi, enter keep block bi + 1
+                        const uint32_t p0e = MaskPrefix<T>::pos(e0);
+                        const uint32_t nq = bi < t_bc ? p0e : t_rlen;
+                        const uint32_t nk = bi + 1u < t_bc ? MaskPrefix<T>::pos(e1) - p0e : kInf;
+                        qcur = cross ? nq : qcur; krem = cross ? nk : krem; bi += cross ? 2u : 0u;
+                        ri += (todo && isr) ? 1u : 0u;
+                        rnext = (uint32_t)rt[ri];                                         // (the guard reads as kInf)
+                        if (emit && ii && io + 1u == ivlen) {
+                            ivk++; ivpos = kInf; ivlen = 0;
+                            if (ivk < t_ic) { const T pk = scr[t_ib + 2 * ivk + 1]; ivlen = (uint32_t)(pk & HM); ivpos = (uint32_t)(pk >> HS); ivleft = scr[t_ib + 2 * ivk]; }
                         }
+                        p += todo ? 1u : 0u;
                     }
                     blk_chk += zsum;
                     wave_sync();
@@ -677,8 +740,12 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const uint32_t nkept = (leaf && ref > 0) ? ((bc + 2u) >> 1) : 0u;
             const uint32_t Ln = leaf ? nkept + ic : 0u;
             const uint32_t lincl = wave_incl_scan32(Ln), lfirst = lincl - Ln, Q = lane_get(lincl, 63);
+#ifdef BVG_ABLATE_LEAF
+            if (false)
+#endif
             for (uint32_t d0 = 0; d0 < Q; d0 += 64) {
                 const bool dl = d0 + lane < Q;
+                BVG_WC(15, 1);
                 const uint32_t iown = task_owner(lincl, d0 + lane);
                 const int il = dl ? (int)iown : (int)lane;
                 const uint32_t i_first = (uint32_t)__shfl((int)lfirst, il, 64), i_nk = (uint32_t)__shfl((int)nkept, il, 64), i_bc = (uint32_t)__shfl((int)bc, il, 64);
@@ -716,7 +783,11 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     const T* const src = pool + (iota ? 0u : b0);
                     uint64_t lsum = 0;
                     const uint32_t nmax = wave_max32(n);
+                    BVG_WC(10, 1); BVG_WC(11, (nmax + 3u) >> 2); BVG_WCL(12, n);
                     const uint32_t tqL2 = BVG_T0();
+#ifdef BVG_ABLATE_LEAFLOOP
+                    if (false)
+#endif
                     for (uint32_t i = 0; i < nmax; i += 4) {
                         const T v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];   // (reads past a run stay inside the LDS allocation)
                         lsum += mix_node<T>(c_k0, i < n ? c_k1 : 0u, iota ? (T)(b0 + i) : v0, nb_lo, nbz);
@@ -761,6 +832,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         if (a.dbg & 64u) {
             for (int i = 0; i < 10; i++) atomicAdd(&a.acc[9 + i], (unsigned long long)cyc[i]);
             atomicAdd(&a.acc[20], (unsigned long long)cyc[10]); atomicAdd(&a.acc[21], (unsigned long long)cyc[11]);
+            for (int i = 12; i < 16; i++) atomicAdd(&a.acc[12 + i], (unsigned long long)cyc[i]);
         }
 #endif
     }
