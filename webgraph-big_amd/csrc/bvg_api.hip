@@ -702,6 +702,16 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             off += pd.count[0];
             size_t offc[12]; { size_t o = 0; for (int c = 0; c < 12; c++) { offc[c] = o; o += pd.count[c]; } }
             const bool tier0_first = knob("BVG_ORDER") && atoi(knob("BVG_ORDER")) == 1;
+            // side streams: [0] the giants and, behind them, the smallest class (short); [1..3] one per larger LDS class, so that every
+            // class starts with the main launch and overlaps it.  (One stream per class and one for the giants made six streams: the
+            // largest class then started only when the last giant batch had finished -- streams share hardware queues -- and ended 11 ms
+            // after everything else at full size; three side streams were 11 % slower, profiles/r03_ab_smap.txt.)
+            const int smap = knob("BVG_SIDE2") ? atoi(knob("BVG_SIDE2")) : 0;
+            auto side_of = [&](int c) {
+                if (smap == 1) return g->side[c >= 4 ? 1 : c == 3 ? 0 : 2];
+                if (smap == 2) return g->side[c];
+                return g->side[c == 1 ? 0 : c - 1];
+            };
             const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
             auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
@@ -721,14 +731,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (!pd.count[c]) continue;
                 DecodeArgs ac = a; ac.work_list = pd.d_lists + offc[c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_rows_any(ac, pd.count[c], g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c], true); alone(g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c]);   // a side stream per class: a short class queued behind a long one ran after everything else had finished
+                launch_rows_any(ac, pd.count[c], side_of(c), true); alone(side_of(c));
                 launches++;
             }
             for (int c = 4; c >= 1; c--) {                                     // the same classes of the lean scan kernel
                 if (!pd.count[7 + c]) continue;
                 DecodeArgs ac = af; ac.work_list = pd.d_lists + offc[7 + c];
                 ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_scan_decode(ac, pd.count[7 + c], g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c]); alone(g->side[knob("BVG_SIDE2") ? 1 + (c & 1) : c]);
+                launch_scan_decode(ac, pd.count[7 + c], side_of(c)); alone(side_of(c));
                 launches++;
             }
             if (pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], g->stream); launches++; alone(g->stream); }

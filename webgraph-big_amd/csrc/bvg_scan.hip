@@ -252,7 +252,8 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         const uint32_t tq7 = BVG_T0();
         // ------------------------------------------------------------------ phase 1: every lane parses the header of its record
         uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
-        int64_t extra = d;
+        int32_t extra = (int32_t)d;                                           // (32-bit arithmetic from here on: the lists of this kernel hold 32-bit ids,
+        uint32_t big = 0;                                                     //  and a code value that would not fit fails the block)
         bool parse = needed && lane < K1 && d > 0;
         // ---- A: reference and block count (BVG:1015-1021)
         if (parse) {
@@ -278,23 +279,31 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         uint32_t btot = lane_get(bincl, K1 - 1);
         // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
         uint32_t rlenN = 0;
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+        uint32_t ncop_sim = 0;
+#endif
         if (parse && lane < K1) {
             if (ref > 0) {
-                int64_t copied = 0, tot = 0;
+                uint32_t copied = 0, tot = 0;
                 for (uint32_t i = 0; i < bc; i++) {
                     const uint32_t lb = gamma_at(stage, rel, v);
                     if (lb == 0 || rel > pend) { bad = true; bc = i; break; }
                     rel += lb;
+                    big |= (uint32_t)(v >> 16) | (uint32_t)(v >> 32);         // (a block of 2^16 elements or more: no list of this kernel is that long)
                     const uint32_t b = (uint32_t)v + (i ? 1u : 0u);
                     tot += b;
-                    if (!(i & 1)) copied += b;
+                    copied += (i & 1) ? 0u : b;
                     // straight in PREFIX form (MaskPrefix): end position of block i in the referenced list | elements kept up to and including it
-                    scr[sb + i] = MaskPrefix<T>::pack((uint32_t)tot, (uint32_t)copied);
+                    scr[sb + i] = MaskPrefix<T>::pack(tot, copied);
                 }
                 rlenN = nd_d[(uint32_t)(x - ref) & RM];
-                if (!(bc & 1)) copied += (int64_t)rlenN - tot;                // BVG:1030
-                extra = (int64_t)d - copied;
-                if (tot > (int64_t)rlenN || tot > 0xFFFF || extra < 0 || copied < 0) bad = true;   // (cannot happen in a validated block)
+                if (big != 0 || tot > rlenN || tot > 0xFFFFu) { bad = true; tot = rlenN; }   // (cannot happen in a validated block)
+                if (!(bc & 1)) copied += rlenN - tot;                         // BVG:1030
+                extra = (int32_t)d - (int32_t)copied;
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+                ncop_sim = copied;
+#endif
+                if (extra < 0) bad = true;
             }
             if (extra > 0 && minint != 0) {                                   // always gamma
                 const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
@@ -315,21 +324,23 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals
         if (parse) {
             if (ic > 0) {
-                int64_t prev = 0;
+                uint32_t prev = 0;
                 for (uint32_t i = 0; i < ic; i++) {
                     uint64_t v1, v2;
                     const uint32_t l1 = gamma_at(stage, rel, v1);
                     const uint32_t l2 = gamma_at(stage, rel + l1, v2);
                     if (l1 == 0 || l2 == 0 || rel > pend) { bad = true; ic = i; break; }
                     rel += l1 + l2;
-                    const int64_t leftv = i == 0 ? x + nat2int64(v1) : prev + 1 + (int64_t)v1;
-                    const int64_t len = (int64_t)v2 + minint;
-                    if (len > 0xFFFFFF) bad = true;                           // (a run descriptor holds 24 bits of length: leave such a list to the row kernel)
+                    big |= (uint32_t)(v1 >> 32) | (uint32_t)(v2 >> 23) | (uint32_t)(v2 >> 32);   // (a run descriptor holds 24 bits of length: leave a longer interval to the row kernel)
+                    const uint32_t u1 = (uint32_t)v1;
+                    const uint32_t leftv = i == 0 ? (uint32_t)x + ((u1 >> 1) ^ (0u - (u1 & 1u))) : prev + 1u + u1;   // nat2int, modulo 2^32
+                    const uint32_t len = (uint32_t)v2 + minint;
                     prev = leftv + len;
-                    extra -= len;
+                    extra -= (int32_t)len;
+                    bad |= extra < 0;                                         // (checked at every step: the difference must not wrap)
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
-                if (extra < 0) { bad = true; extra = 0; }
+                if (extra < 0 || big != 0) { bad = true; extra = 0; }
             }
             nres = (uint32_t)extra;
         }
@@ -387,7 +398,13 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         }
         // a stored list without reference is emitted from its parked residuals (they play the referenced list): those are summed
         // there; every other residual is summed when it is decoded
-        const uint32_t k1d = (stored && ref == 0) ? 0u : k1;
+        // ... unless it has no intervals either: then the list IS its residuals, decoded straight into its place (nothing parked, no level)
+#ifdef BVG_NO_DIRECT
+        const bool direct = false;
+#else
+        const bool direct = stored && ref == 0 && ic == 0;
+#endif
+        const uint32_t k1d = (stored && ref == 0 && !direct) ? 0u : k1;
         // skip entries of the super-row, in node order
         const uint32_t cntE = (parse && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
         uint32_t efirst;
@@ -408,7 +425,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const uint32_t avail = CAP - pool_used;
             const bool cand = on1 && lane >= sa;
             const uint32_t size = (cand && stored) ? dclamp : 0u;
-            const uint32_t rsz = (cand && stored) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
+            const uint32_t rsz = (cand && stored && !direct) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
             const uint32_t sincl = wave_incl_scan32(size), rincl = wave_incl_scan32(rsz);
             const bool fits = lane >= sa && lane < K1 && (uint64_t)sincl + rincl <= avail;
             const uint32_t se = sa + (uint32_t)__popcll(ballot(fits));          // (the sums are prefixes: `fits` is a contiguous run from sa)
@@ -466,7 +483,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                         const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64), s_ce = (uint32_t)__shfl((int)ce, nl, 64);
                         const uint32_t q = tl[u] ? (isl ? t - s_ts : s_ce) : 0u;
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
-                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? rtb : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
+                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? (direct ? base : rtb) : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
                         tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
                         const uint32_t t0 = q * kSkipEvery;
@@ -520,10 +537,11 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                             const uint32_t tn = trel[u] + len[u];
                             if (on[u] && taddr[u] != kInf) pool[taddr[u] + i] = rn;
                             csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
-                            r[u] = on[u] ? rn : r[u]; trel[u] = on[u] ? tn : trel[u];
-                            if (on[u] && tn > tpend[u]) { tbad = true; cnt[u] = 0; }
+                            r[u] = rn; trel[u] = on[u] ? tn : trel[u];              // (a lane past its task keeps adding to r: nobody reads it)
                         }
                     }
+#pragma unroll
+                    for (uint32_t u = 0; u < RU; u++) tbad |= trel[u] > tpend[u];    // ran past the record: checked once, behind the loop (reads past it are harmless)
                 }
                 };
                 if (Ttot > 96u) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
@@ -538,7 +556,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                         if (len == 0) { bad = true; break; }
                         rr += len;
                         r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
-                        if (stored) pool[rtb + t] = r;
+                        if (stored) pool[(direct ? base : rtb) + t] = r;
                         csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
                         if (rr > pend) { bad = true; break; }
                     }
@@ -572,7 +590,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 const bool ch = nl != lvl; lvl = nl;
                 if (!ballot(ch)) break;
             }
-            const bool emits = emitn && stored;
+            const bool emits = emitn && stored && !direct;
             if (emits) pool[rtb + nres] = sentinel<T>();                      // guard behind the node's residual positions
             uint64_t remaining = ballot(emits);
             wave_sync();
@@ -592,7 +610,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
 #endif
                     for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
                         const bool tl = p0 + lane < Itot;
-                        BVG_WC(3, 1); BVG_WCL(13, tl ? 1u : 0u);
+                        BVG_WC(3, 1);
                         const uint32_t own = task_owner(iincl2, p0 + lane);       // (every lane takes part in the shuffles)
                         const int nl = tl ? (int)own : (int)lane;
                         const uint32_t s_first = (uint32_t)__shfl((int)is, nl, 64);
@@ -637,8 +655,19 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 }
                 BVG_T1(3, tq3);
                 const uint32_t tq1 = BVG_T0();
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+                {   // what a level would take with tasks cut by kept rank (K) / by the longer of the kept and the residual stream (M)
+                    const uint32_t nk = mem ? (pure ? nres : ncop_sim) : 0u, nr = mem ? nresN : 0u, mj = nk > nr ? nk : nr;
+                    uint32_t SK = (wave_sum32(nk) + 63u) >> 6; if (SK < kMinTask) SK = kMinTask;
+                    uint32_t SM = (wave_sum32(mj) + 63u) >> 6; if (SM < kMinTask) SM = kMinTask;
+                    const uint32_t TK = mem ? (nk + SK - 1u) / SK + (nk == 0 ? 1u : 0u) : 1u, TM = mem ? (mj + SM - 1u) / SM + (mj == 0 ? 1u : 0u) : 1u;
+                    BVG_WC(12, wave_max32(mem ? (d + TK - 1u) / TK : 0u)); BVG_WC(13, wave_max32(mem ? (d + TM - 1u) / TM : 0u));
+                }
+#endif
                 // ---------------- Z2: tasks of S output positions, all equally long
-                const uint32_t Wl = wave_sum32(mem ? d : 0u);
+                // S in one step: sum_i ceil(d_i / S) <= W / S + N - N / S < 64 once S >= W / (64 - N)  (N lists, W positions in all)
+                const uint32_t Wl = wave_sum32(mem ? d : 0u), Nl = (uint32_t)__popcll(ballot(mem));
+#ifdef BVG_OLD_S
                 uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
                 uint32_t Tn = 0;
                 for (int it = 0; it < 6; it++) {
@@ -649,6 +678,12 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     const uint32_t s2 = (uint32_t)((float)S * (float)tt * (1.0f / 64.0f));
                     S = s2 > S ? s2 : S + 1u;
                 }
+#else
+                uint32_t S = Nl < 64u ? (Wl + (63u - Nl)) / (64u - Nl) : 0x7FFFFFFFu;
+                if (S < kMinTask) S = kMinTask;
+                uint32_t Tn = 0;
+                if (mem) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
+#endif
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
                 BVG_T1(1, tq1);
 #ifdef BVG_ABLATE_Z2
@@ -783,7 +818,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     const T* const src = pool + (iota ? 0u : b0);
                     uint64_t lsum = 0;
                     const uint32_t nmax = wave_max32(n);
-                    BVG_WC(10, 1); BVG_WC(11, (nmax + 3u) >> 2); BVG_WCL(12, n);
+                    BVG_WC(10, 1); BVG_WC(11, (nmax + 3u) >> 2);
                     const uint32_t tqL2 = BVG_T0();
 #ifdef BVG_ABLATE_LEAFLOOP
                     if (false)
