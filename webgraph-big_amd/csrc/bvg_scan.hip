@@ -310,6 +310,17 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 bad |= l == 0 || v > (pend - rel) / 2 + 1; rel += l; ic = bad ? 0u : (uint32_t)v;
             }
         }
+        // The next super-row's first W records decide which of this one's last lists are copied from (see below); they mostly lie
+        // behind the staged window, so their first 12 bytes are fetched from memory here and looked at after the intervals.
+        uint32_t pk0 = 0, pk1 = 0, pk2 = 0; bool peeked = false;
+        {
+            const int64_t nx = r0 + K1 + lane;
+            const uint64_t pb = (nxt_off >> 5) << 2;
+            if (K1 == K1win && lane < W && nx < e && !(nxt_off >= stg_bit0 && nxt_off + 160 <= stg_bit0 + stg_bits) && pb + 12 <= a.padded_bytes) {
+                const uint32_t* gp = reinterpret_cast<const uint32_t*>(a.graph + pb);
+                pk0 = gp[0]; pk1 = gp[1]; pk2 = gp[2]; peeked = true;
+            }
+        }
         const uint32_t iw = lane < K1 ? 2 * ic : 0u;
         const uint32_t iincl = wave_incl_scan32(iw > SCRH ? SCRH + 1 : iw);
         // the copy blocks may have taken the whole area: halve the super-row until the first node's intervals fit
@@ -369,7 +380,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const int64_t nx = r0 + K1 + lane;
             if (lane < W && nx < e) {
                 unknown = true;
-                if (nxt_off >= stg_bit0 && nxt_end + 96 <= stg_bit0 + stg_bits) {
+                if (nxt_off >= stg_bit0 && nxt_off + 160 <= stg_bit0 + stg_bits) {
                     uint32_t prel = (uint32_t)(nxt_off - stg_bit0);
                     uint64_t pv;
                     const uint32_t l = gamma64(win64<LIN>(stage, prel), pv);
@@ -382,13 +393,30 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                             else if (lz >= 64) unknown = true;
                         }
                     }
+                } else if (peeked && K1 == K1win) {                                           // the 12 bytes fetched above
+                    const uint32_t sh = (uint32_t)nxt_off & 31u;
+                    const uint64_t hi = ((uint64_t)__builtin_bswap32(pk0) << 32) | __builtin_bswap32(pk1);
+                    const uint64_t win = sh ? (hi << sh) | (uint64_t)(__builtin_bswap32(pk2) >> (32u - sh)) : hi;
+                    uint64_t pv;
+                    const uint32_t l = gamma64(win, pv);
+                    if (l != 0 && l <= 48) {
+                        unknown = false;
+                        if (pv != 0) {
+                            const uint64_t w = win << l;
+                            const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                            if (lz >= 64u - l) unknown = true;                                 // (the unary code runs past the 64 bits at hand)
+                            else if (lz > lane && lz <= W && lz - lane <= K1) tgt = K1 + lane - lz;
+                        }
+                    }
                 }
             }
             if (ballot(unknown)) refmask |= K1 >= W ? (~0ull << (K1 - W)) : ~0ull;
+            BVG_WC(13, ballot(unknown) ? 1u : 0u);
             for (uint32_t j = 0; j < W && j < 64; j++) { const uint32_t t = lane_get(tgt, j); if (t < 64) refmask |= 1ull << t; }
         }
         BVG_T1(15, tqp);
         const bool stored = (refmask >> lane) & 1ull;
+        BVG_WC(12, __popcll(ballot(stored && on1)));
         const bool repn = on1 && x >= rep_lo && x < rep_hi;
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
         uint32_t k0 = 0, k1 = 0;
@@ -655,15 +683,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 }
                 BVG_T1(3, tq3);
                 const uint32_t tq1 = BVG_T0();
-#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
-                {   // what a level would take with tasks cut by kept rank (K) / by the longer of the kept and the residual stream (M)
-                    const uint32_t nk = mem ? (pure ? nres : ncop_sim) : 0u, nr = mem ? nresN : 0u, mj = nk > nr ? nk : nr;
-                    uint32_t SK = (wave_sum32(nk) + 63u) >> 6; if (SK < kMinTask) SK = kMinTask;
-                    uint32_t SM = (wave_sum32(mj) + 63u) >> 6; if (SM < kMinTask) SM = kMinTask;
-                    const uint32_t TK = mem ? (nk + SK - 1u) / SK + (nk == 0 ? 1u : 0u) : 1u, TM = mem ? (mj + SM - 1u) / SM + (mj == 0 ? 1u : 0u) : 1u;
-                    BVG_WC(12, wave_max32(mem ? (d + TK - 1u) / TK : 0u)); BVG_WC(13, wave_max32(mem ? (d + TM - 1u) / TM : 0u));
-                }
-#endif
                 // ---------------- Z2: tasks of S output positions, all equally long
                 // S in one step: sum_i ceil(d_i / S) <= W / S + N - N / S < 64 once S >= W / (64 - N)  (N lists, W positions in all)
                 const uint32_t Wl = wave_sum32(mem ? d : 0u), Nl = (uint32_t)__popcll(ballot(mem));
