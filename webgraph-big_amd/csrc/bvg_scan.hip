@@ -181,7 +181,6 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         if (livelane && my_base != kNoList) nd_base[(uint32_t)y & RM] = (uint16_t)nbase;
         pool_used = lane_get(nincl, 63);
         wave_sync();
-        BVG_WC(5, pool_used);                                             // (work-count build: elements carried over, per compaction: slot 3 below counts them)
     };
 
     int64_t r0 = hs;
@@ -411,12 +410,14 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 }
             }
             if (ballot(unknown)) refmask |= K1 >= W ? (~0ull << (K1 - W)) : ~0ull;
-            BVG_WC(13, ballot(unknown) ? 1u : 0u);
             for (uint32_t j = 0; j < W && j < 64; j++) { const uint32_t t = lane_get(tgt, j); if (t < 64) refmask |= 1ull << t; }
         }
         BVG_T1(15, tqp);
         const bool stored = (refmask >> lane) & 1ull;
-        BVG_WC(12, __popcll(ballot(stored && on1)));
+        BVG_WC(12, __popcll(ballot(stored && on1)));                          // (work-count build: stored lists | reference-free with intervals | with reference and extras | direct)
+        BVG_WC(13, __popcll(ballot(stored && on1 && ref == 0 && ic != 0)));
+        BVG_WC(9, __popcll(ballot(stored && on1 && ref != 0 && (ic != 0 || nres != 0))));
+        BVG_WC(14, __popcll(ballot(stored && on1 && ref == 0 && ic == 0)));
         const bool repn = on1 && x >= rep_lo && x < rep_hi;
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
         uint32_t k0 = 0, k1 = 0;
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const bool rparse = parse && act;
             uint64_t csum = 0;
 #if defined(BVG_PROF) && defined(BVG_PROF_WORK)
-            if (!(sk_n != 0 && ballot(rparse && cntE != 0))) { BVG_WC(9, wave_max32(rparse ? nres : 0u)); BVG_WCL(14, rparse ? nres : 0u); }
+            (void)0;
 #endif
             if (sk_n != 0 && ballot(rparse && cntE != 0)) {
                 // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task.  Long tasks first
@@ -739,7 +740,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     }
                     const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
                     uint64_t zsum = 0;
-                    // BVG_WCL(5, pstop - p);
+                    BVG_WCL(5, pstop - p);
                     BVG_T1(2, tq2);
                     const uint32_t tq4 = BVG_T0();
                     // One output position per step and lane.  With some fifty lanes at work nearly every step sees a lane at the end of a
