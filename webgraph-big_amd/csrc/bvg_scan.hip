@@ -18,11 +18,19 @@
 //     list in LDS (read off the prefix form of the blocks), an interval is an iota.  The runs of a sub-row are cut into chunks of kChunk
 //     elements dealt to all 64 lanes; a chunk is straight-line groups of {4 LDS reads in flight, 4 mixes}: no per-element block
 //     bookkeeping, no branch inside a chunk;
-//   * stored lists are built as in the row kernel (emission by output position, level by level);
+//   * stored lists are built as in the row kernel (emission by output position, level by level; block ends and residual positions
+//     are handled without branches in the position loop) -- except a stored list without reference and without intervals, which IS
+//     its residuals: they are decoded straight into its place (nothing parked, no level, no position task);
+//   * which of the last W lists of a super-row the NEXT super-row copies from is read off that one's records: from the staged window
+//     when they lie in it, else from 12 bytes fetched from memory while the intervals are parsed;
 //   * flat tasks (residual segments, extras, position tasks, chunks) are dealt to lanes by a binary search over the prefix sums of the
 //     task counts with six shuffles (task_owner) -- no task maps in LDS, no loop over a lane's tasks.
-// At 14 wavefronts per CU the kernel is bound by vector-instruction issue (profiles/r03_pmc_*): hiding more latency (prefetching the
-// next window or the skip entries into registers, more wavefronts) no longer moves it; fewer instructions per arc do.
+// At 14 wavefronts per CU the kernel is bound by vector-instruction issue (profiles/r03_eu15_pmc_summary.txt, r03_ab_dummy.txt: an
+// added VALU instruction costs exactly its issue time): hiding more latency (prefetching the next window or the skip entries into
+// registers, 16 wavefronts with the pool they leave) does not move it; fewer instructions per arc do.
+// Builds for measuring: -DBVG_PROF (wave-cycles per section), -DBVG_PROF -DBVG_PROF_WORK (`make work`: passes / steps / elements of
+// every loop instead), -DBVG_MARKS (section boundaries as comments in `hipcc -S` output), -DBVG_ABLATE_{Z1,Z2,Z2LOOP,RESLOOP,LEAF,
+// LEAFLOOP} (a section compiled out: wrong results, its share of the time), -DBVG_EXP_DUMMY=n (n VALU instructions added per loop step).
 //
 // A block that does not fit (pool, window, scratch) fails over to the row kernel's tiers like any other; a block without the
 // validation mark never gets here (the host sorts on it).
