@@ -143,3 +143,49 @@ def test_blocks_with_overlapping_streams_never_reach_the_scan_kernel(W, tools, o
         assert _same(r, o)
     assert r["lean_blocks"] > 0 and r["slow_blocks"] > 0, r
     hg.close()
+
+
+def test_reference_free_lists_decoded_in_place_and_copied_across_super_rows(W, oracle):
+    """Hand-assembled records: every fourth node holds a long list WITHOUT reference and WITHOUT intervals (the scan kernel decodes such
+    a stored list straight into its place: nothing parked, no position task), the three nodes after it copy from it with reference 1, 2
+    and 3 (all kept / a prefix / two kept blocks) and add residuals of their own (BVGraph.java:1062-1090).  The records are large (up to
+    ~2 000 bits), so a super-row holds a handful of them, ends wherever the window ends, and the references of the next one are read
+    from memory, not from the window."""
+    rng = np.random.default_rng(77)
+    n = 6000
+    recs, lists = [], []
+    for x in range(n):
+        lo, hi = max(0, x - 2500), min(n, x + 2500)
+        if x % 4 == 0:
+            l = sorted(int(v) for v in rng.choice(np.arange(lo, hi), size=int(rng.integers(40, 160)), replace=False))
+            recs.append(Record(d=len(l), residuals=l))
+        else:
+            ref = x % 4
+            base = lists[x - ref]
+            if ref == 1: blocks, kept = [], list(base)                                   # no blocks: everything is kept (BVG:1030)
+            elif ref == 2: k = len(base) // 2; blocks, kept = [k], base[:k]              # one block: a prefix
+            else:
+                k1, k2 = len(base) // 4, len(base) // 3
+                blocks, kept = [k1, k2], base[:k1] + base[k1 + k2:]                      # keep, skip, keep the rest
+            pool = np.setdiff1d(np.arange(lo, hi), np.array(kept, dtype=np.int64))
+            extra = sorted(int(v) for v in rng.choice(pool, size=int(rng.integers(0, 30)), replace=False))
+            l = sorted(kept + extra)
+            recs.append(Record(d=len(l), ref=ref, blocks=blocks, residuals=extra))
+        lists.append(l)
+    gbytes, offs, expect = assemble(recs)
+    assert expect == lists
+    p = W.default_params().clone(nodes=n, arcs=int(sum(len(l) for l in lists)))
+    og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), gbytes, offs)
+    g = W.BVGraph.from_memory(p, np.frombuffer(gbytes, dtype=np.uint8), offs)
+    o = og.scan()
+    assert o["arcs"] == p.arcs
+    for _ in range(3):
+        r = g.scan()
+        assert _same(r, o)
+    assert r["lean_blocks"] >= 0.9 * (r["lean_blocks"] + r["slow_blocks"]), r
+    for a, b in ((1, n - 1), (1234, 4321), (4001, 4003)):
+        ra, oa = g.scan(a, b), og.scan(a, b)
+        assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (a, b)
+    deg, succ = g.decode_range(0, n)                                           # the materialising kernels on the same stream
+    assert succ.tolist() == [v for l in lists for v in l]
+    g.close()
