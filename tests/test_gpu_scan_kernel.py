@@ -12,7 +12,7 @@ from bvrecords import Record, assemble
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL", "BVG_SCAN_WAVES", "BVG_GIANT")
+KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL", "BVG_SCAN_WAVES", "BVG_GIANT", "BVG_WIDE_HALF")
 
 
 @pytest.fixture(autouse=True)
@@ -188,4 +188,35 @@ def test_reference_free_lists_decoded_in_place_and_copied_across_super_rows(W, o
         assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (a, b)
     deg, succ = g.decode_range(0, n)                                           # the materialising kernels on the same stream
     assert succ.tolist() == [v for l in lists for v in l]
+    g.close()
+
+
+@pytest.mark.parametrize("half", [None, "2500"])
+def test_wide_graphs_take_the_scan_kernel_with_block_relative_ids(W, tools, oracle, monkeypatch, half):
+    """Graphs beyond 2^32 nodes (here: the 64-bit path forced on a small graph) run the same scan kernel on 32-bit lists of ids RELATIVE to
+    a per-block base 2^31 below the block's first node; a block holding an id outside its 2^32-id window stays with the 64-bit row
+    kernel.  With the window shrunk to 2 x 2 500 ids around each block both happen, and every result is the oracle's."""
+    if half: monkeypatch.setenv("BVG_WIDE_HALF", half)
+    n = 30000
+    st = tools.synth_store(n, seed=47, synth=tools.eu_like(), threads=4)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    g.set_tuning(force_wide=True)
+    og = _og(oracle, st)
+    o = og.scan()
+    g.build_index()
+    for _ in range(3):
+        r = g.scan()
+        assert _same(r, o), half
+    assert r["lean_blocks"] > 0, r
+    if half: assert r["slow_blocks"] > 0, r                             # blocks with far successors
+    else: assert r["lean_blocks"] >= 0.6 * (r["lean_blocks"] + r["slow_blocks"]), r
+    for base in ((1 << 40) + 1, 0xFFFFF000):
+        g.set_node_base(base)
+        assert g.scan()["chk"] == og.scan(0, n, node_base=base)["chk"], (half, base)
+    g.set_node_base(0)
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        a, b = sorted(int(v) for v in rng.integers(0, n + 1, 2))
+        ra, oa = g.scan(a, b), og.scan(a, b)
+        assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (half, a, b)
     g.close()

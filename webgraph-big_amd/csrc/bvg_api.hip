@@ -440,6 +440,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         a.pass_cost = knob("BVG_PASSCOST") ? (uint32_t)strtoul(knob("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
+    a.wide_half = knob("BVG_WIDE_HALF") ? strtoull(knob("BVG_WIDE_HALF"), nullptr, 10) : 0x80000000ull;
     if (!batch && rows_default && skx && skx->wide == wide) {
         a.skip_first = skx->d_first; a.skip_bit = skx->d_bit; a.skip_val = skx->d_val; a.skip_fmt = skx->d_fmt;
     }
@@ -599,6 +600,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         }
         const uint32_t max_pool = wide ? 6144 : 12288;
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
+        const uint32_t lclasses[4] = {2048, 4096, 8192, 12288};               // the lean scan kernel's lists are 32-bit on every graph (block-relative ids beyond 2^32 nodes)
         const bool predict = !batch && !stream && !legacy && pl.h_maxd.size() == pl.nblk && !knob("BVG_NOPREDICT");
         // The lean scan kernel (bvg_scan.hip) takes the blocks that the index-building pass has validated: scans with 32-bit
         // successors and the default codings, index present.  BVG_SCANK=0 keeps every block on the row kernel (tests, A/B runs).
@@ -607,7 +609,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         {
             const Codings& c = a.cod;
             const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-            fast_ok = predict && !materialise && !wide && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default && a.skip_first && a.skip_fmt && skx &&
+            fast_ok = predict && !materialise && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default && a.skip_first && a.skip_fmt && skx &&
                       skx->h_fmt.size() == pl.nblk && !wg_nw && !flow && !(knob("BVG_SCANK") && atoi(knob("BVG_SCANK")) == 0);
             if (fast_ok) {
                 // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
@@ -657,8 +659,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     int c;
                     if (long_record) c = 5;
                     else if (fastb ? (md / 2 + 64 <= af.lds_pool_elems) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
-                    else { c = 1; while (c < 5 && classes[c - 1] < need) c++; }
-                    if (pd.learned[lo + i] > c) { c = pd.learned[lo + i]; if (c >= 5 && gneed < 65536) gneed = 65536; }   // learned from an earlier scan's cascade
+                    else { c = 1; while (c < 5 && (fastb ? lclasses : classes)[c - 1] < need) c++; }
+                    int lrn = pd.learned[lo + i];                              // learned from an earlier scan's cascade -- in classes of the ROW kernel, whose
+                    if (fastb && wide && lrn) lrn = std::max(1, lrn - 1);       // 64-bit lists take twice the bytes: the lean class one below holds as many elements
+                    if (lrn > c) { c = lrn; if (c >= 5 && gneed < 65536) gneed = 65536; }
                     if (c == 5 && !giant_ok) c = 6;
                     if (c >= 5 && need > gneed) gneed = need;
                     L[(fastb && c <= 4) ? 7 + c : c].push_back(lo + i);
@@ -680,12 +684,15 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (ngiant) {
                 // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
                 gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : 8192u);
+                // (a batch lasts as long as its longest lists, 33-45 ms whatever its size, and batches run one after the other: a scan with very
+                //  many giants -- 157 k on the 4.4 G-node workload, 29 batches = 2.05 s of a scan whose tier 0 took 1.24 s -- gets larger ones)
+                const bool many = ngiant > 65536u;
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : (many ? 16384u : 8192u));
                 {   // every giant block of the scan in one launch where memory allows (batches run one after the other on their side
                     // stream, and the first one shares the chip with tier 0 for the whole scan: profiles/r03_ktrace_d14.txt), at most 1/8 of what is free
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / 8;
+                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / (many ? 3 : 8);
                         gbatch = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(gbatch, room / std::max<uint64_t>(per, 1)), std::min<uint32_t>(ngiant, 256u));
                     }
                 }
@@ -715,7 +722,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
             auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
-            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], g->stream); launches++; alone(g->stream); }
+            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, g->stream); launches++; alone(g->stream); }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
@@ -738,11 +745,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             for (int c = 4; c >= 1; c--) {                                     // the same classes of the lean scan kernel
                 if (!pd.count[7 + c]) continue;
                 DecodeArgs ac = af; ac.work_list = pd.d_lists + offc[7 + c];
-                ac.lds_pool_elems = classes[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, classes[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_scan_decode(ac, pd.count[7 + c], side_of(c)); alone(side_of(c));
+                ac.lds_pool_elems = lclasses[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, lclasses[c - 1] / 4); ac.lds_stage_words = 1024;
+                launch_scan_decode(ac, pd.count[7 + c], wide, side_of(c)); alone(side_of(c));
                 launches++;
             }
-            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], g->stream); launches++; alone(g->stream); }
+            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));

@@ -65,6 +65,7 @@ struct DecodeArgs {
     int window, min_interval;
     Codings cod;
     uint64_t node_base;
+    uint64_t wide_half;                 // lean scan kernel on graphs beyond 2^32 nodes: the block base lies this far below the block's first node (2^31; tests shrink it)
     unsigned long long* acc;            // [0] arcs [1] chk [2] nodes [3] error bits (+ debug counters) of stripe 0
     uint32_t acc_mask;                  // the block results are striped over acc_mask+1 copies of those four words, kAccStride words apart
                                         // (one address for every block costs ~12 ns per atomic: 9 ms per GiB of 4 KiB blocks), summed by reduce_acc
@@ -99,7 +100,7 @@ void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materi
 // the lean LDS-resident row kernel (bvg_rows.hip): tiers 0 and 1
 void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 // the lean scan kernel (bvg_scan.hip): validated blocks of a scan, 32-bit successors, default codings, skip index present
-void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s);
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, hipStream_t s);
 size_t scan_static_lds();
 
 // the offsets index from a bare .graph in parallel (bvg_derive.hip): chunks of the stream walked speculatively, one code per lane and step, and iterated

@@ -101,7 +101,7 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
 }
 
 // NBZ: the node base is 0 (no carry handling in the checksum key); Z3: zeta_3 residuals (the specialised decoder)
-template <bool NBZ, bool Z3>
+template <bool NBZ, bool Z3, bool WIDE>
 __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
@@ -125,7 +125,13 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
-    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
+    // WIDE (graphs of more than 2^32 - 256 nodes): the lists still hold 32-bit elements -- ids RELATIVE to a per-block base B, 2^31 below the
+    // block's first node.  Successors of a web graph lie near their node; a block with an id outside [B, B + 2^32) fails (every id that enters
+    // a list is checked where it is made: residuals, skip values, interval ends; copied elements come from checked lists) and stays with
+    // the 64-bit row kernel.  The checksum takes the base like a node base (mix_node: m + base, carries included).
+    const int64_t B = WIDE ? (s > (int64_t)a.wide_half ? s - (int64_t)a.wide_half : 0) : 0;
+    const uint64_t nbase = a.node_base + (uint64_t)B;
+    const uint32_t nb_lo = (uint32_t)nbase, nb_hi = (uint32_t)(nbase >> 32);
     constexpr bool nbz = NBZ;
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
@@ -351,8 +357,12 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     rel += l1 + l2;
                     big |= (uint32_t)(v1 >> 32) | (uint32_t)(v2 >> 23) | (uint32_t)(v2 >> 32);   // (a run descriptor holds 24 bits of length: leave a longer interval to the row kernel)
                     const uint32_t u1 = (uint32_t)v1;
-                    const uint32_t leftv = i == 0 ? (uint32_t)x + ((u1 >> 1) ^ (0u - (u1 & 1u))) : prev + 1u + u1;   // nat2int, modulo 2^32
+                    const uint32_t leftv = i == 0 ? (uint32_t)(x - B) + ((u1 >> 1) ^ (0u - (u1 & 1u))) : prev + 1u + u1;   // nat2int, modulo 2^32
                     const uint32_t len = (uint32_t)v2 + minint;
+                    if (WIDE) {                                               // the interval must lie inside the block's 2^32 ids
+                        const int64_t lt = i == 0 ? (x - B) + nat2int64(v1) : (int64_t)(uint64_t)prev + 1 + (int64_t)v1;
+                        big |= (uint32_t)(((uint64_t)lt) >> 32) | (uint32_t)(((uint64_t)lt + len) >> 32);
+                    }
                     prev = leftv + len;
                     extra -= (int32_t)len;
                     bad |= extra < 0;                                         // (checked at every step: the difference must not wrap)
@@ -526,12 +536,16 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                         const uint32_t t0 = q * kSkipEvery;
                         const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
                         cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
-                        trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)(r0 + nl); tpend[u] = t_pend;
+                        trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)((r0 - B) + nl); tpend[u] = t_pend;
                         tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
                         taddr[u] = t_dst == kInf ? kInf : t_dst + t0;
                         if (tl[u] && q) {
                             const uint64_t ei = sk_base + t_ef + q - 1u;
-                            trel[u] = t_rec + a.skip_bit[ei]; r[u] = reinterpret_cast<const T*>(a.skip_val)[ei];
+                            trel[u] = t_rec + a.skip_bit[ei];
+                            if (WIDE) {                                       // (the index of a wide graph holds 64-bit values)
+                                const uint64_t sv = reinterpret_cast<const uint64_t*>(a.skip_val)[ei] - (uint64_t)B;
+                                r[u] = (T)sv; if (sv >> 32) { tbad = true; cnt[u] = 0; }
+                            } else r[u] = reinterpret_cast<const T*>(a.skip_val)[ei];
                             if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
                         }
                     }
@@ -571,6 +585,10 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                         for (uint32_t u = 0; u < RU; u++) {
                             const T gap = (tfirst[u] && i == 0) ? (T)nat2int64(val[u]) : (T)(1 + (T)val[u]);
                             const T rn = (T)(r[u] + gap);
+                            if (WIDE) {                                       // the id must stay inside the block's 2^32 ids
+                                const int64_t tv = (int64_t)(uint64_t)r[u] + ((tfirst[u] && i == 0) ? nat2int64(val[u]) : (int64_t)(1 + val[u]));
+                                tbad |= on[u] && (((uint64_t)tv) >> 32) != 0;
+                            }
                             const uint32_t tn = trel[u] + len[u];
                             if (on[u] && taddr[u] != kInf) pool[taddr[u] + i] = rn;
                             csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
@@ -585,13 +603,17 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                 bad |= tbad;
             } else if (rparse) {
                 if (nres > 0) {
-                    T r = (T)x;
+                    T r = (T)(x - B);
                     uint32_t rr = rel;
                     for (uint32_t t = 0; t < nres; t++) {
                         uint64_t val;
                         const uint32_t len = read_residual<false>(stage, rr, zfast, zk, a.cod.residual, val);
                         if (len == 0) { bad = true; break; }
                         rr += len;
+                        if (WIDE) {
+                            const int64_t tv = (int64_t)(uint64_t)r + (t == 0 ? nat2int64(val) : (int64_t)(1 + val));
+                            if (((uint64_t)tv) >> 32) { bad = true; break; }
+                        }
                         r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
                         if (stored) pool[(direct ? base : rtb) + t] = r;
                         csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
@@ -906,13 +928,14 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
 // what the kernel needs of LDS besides the pool and the scratch area (static arrays)
 size_t scan_static_lds() { return (size_t)kRing * 4; }
 
-void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, hipStream_t s) {
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, hipStream_t s) {
     if (nblocks == 0) return;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
     const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
-    if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
 
 }  // namespace bvg
