@@ -684,15 +684,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (ngiant) {
                 // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
                 gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                // (a batch lasts as long as its longest lists, 33-45 ms whatever its size, and batches run one after the other: a scan with very
-                //  many giants -- 157 k on the 4.4 G-node workload, 29 batches = 2.05 s of a scan whose tier 0 took 1.24 s -- gets larger ones)
-                const bool many = ngiant > 65536u;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : (many ? 16384u : 8192u));
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : 8192u);   // (larger batches bought nothing on the 157 k giants of the 4.4 G-node run: the kernel's rate is per block)
                 {   // every giant block of the scan in one launch where memory allows (batches run one after the other on their side
                     // stream, and the first one shares the chip with tier 0 for the whole scan: profiles/r03_ktrace_d14.txt), at most 1/8 of what is free
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / (many ? 3 : 8);
+                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / 8;
                         gbatch = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(gbatch, room / std::max<uint64_t>(per, 1)), std::min<uint32_t>(ngiant, 256u));
                     }
                 }
