@@ -298,16 +298,28 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         if (parse && lane < K1) {
             if (ref > 0) {
                 uint32_t copied = 0, tot = 0;
-                for (uint32_t i = 0; i < bc; i++) {
-                    const uint32_t lb = gamma_at(stage, rel, v);
-                    if (lb == 0 || rel > pend) { bad = true; bc = i; break; }
-                    rel += lb;
-                    big |= (uint32_t)(v >> 16) | (uint32_t)(v >> 32);         // (a block of 2^16 elements or more: no list of this kernel is that long)
-                    const uint32_t b = (uint32_t)v + (i ? 1u : 0u);
-                    tot += b;
-                    copied += (i & 1) ? 0u : b;
+                // two blocks per step -- a kept one and the skipped one behind it -- from one 64-bit window: the longest block list of the 64
+                // records sets the number of steps (28 on the eu15 shape, 8 % of the scan at one block per step: profiles/r03_ab_dummyhdr.txt).
+                // A block of 2^16 - 1 elements or more fails the block here (no list of this kernel is that long).
+                for (uint32_t i = 0; i < bc; i += 2) {
+                    const uint64_t w = win64<LIN>(stage, rel);
+                    const uint32_t lz1 = w ? (uint32_t)__builtin_clzll(w) : 64u;
+                    const bool two = i + 1u < bc;
+                    const uint32_t l1 = 2u * (lz1 & 15u) + 1u;
+                    const uint64_t w2 = w << l1;
+                    const uint32_t lz2 = w2 ? (uint32_t)__builtin_clzll(w2) : 64u;
+                    if (lz1 >= 16u || (two && lz2 >= 16u) || rel > pend) { bad = true; bc = i; break; }
+                    const uint32_t l2 = 2u * lz2 + 1u;
+                    const uint32_t b1 = (uint32_t)(w >> (64u - l1)) - (i ? 0u : 1u);        // (gamma value + 1 = the top l1 bits; the first block is not biased)
+                    const uint32_t b2 = (uint32_t)(w2 >> (64u - (l2 & 63u)));               // (value + 1: every block but the first is at least 1)
+                    tot += b1; copied += b1;
                     // straight in PREFIX form (MaskPrefix): end position of block i in the referenced list | elements kept up to and including it
                     scr[sb + i] = MaskPrefix<T>::pack(tot, copied);
+                    if (two) { tot += b2; scr[sb + i + 1u] = MaskPrefix<T>::pack(tot, copied); }
+                    rel += l1 + (two ? l2 : 0u);
+#ifdef BVG_EXP_DUMMY_HDR
+                    { uint32_t dm = i; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY_HDR; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
+#endif
                 }
                 rlenN = nd_d[(uint32_t)(x - ref) & RM];
                 if (big != 0 || tot > rlenN || tot > 0xFFFFu) { bad = true; tot = rlenN; }   // (cannot happen in a validated block)
@@ -355,6 +367,9 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     const uint32_t l2 = gamma_at(stage, rel + l1, v2);
                     if (l1 == 0 || l2 == 0 || rel > pend) { bad = true; ic = i; break; }
                     rel += l1 + l2;
+#ifdef BVG_EXP_DUMMY_IV
+                    { uint32_t dm = i; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY_IV; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
+#endif
                     big |= (uint32_t)(v1 >> 32) | (uint32_t)(v2 >> 23) | (uint32_t)(v2 >> 32);   // (a run descriptor holds 24 bits of length: leave a longer interval to the row kernel)
                     const uint32_t u1 = (uint32_t)v1;
                     const uint32_t leftv = i == 0 ? (uint32_t)(x - B) + ((u1 >> 1) ^ (0u - (u1 & 1u))) : prev + 1u + u1;   // nat2int, modulo 2^32
