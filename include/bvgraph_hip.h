@@ -260,7 +260,8 @@ int bvg_mosaic(const bvg_graph* const* bases, int k, int64_t cycles, bvg_graph**
 /* ---- tuning knobs (optional) ---- */
 typedef struct bvg_tuning {
     uint32_t block_bits;     /* target compressed bits per node block (one wavefront each); 0 = default */
-    uint32_t force_wide;     /* 1 = use the 64-bit successor kernels even when every node id fits 32 bits (nodes <= 2^32 - 256) */
+    uint32_t force_wide;     /* 1 = use the 64-bit successor kernels even when every node id fits 32 bits (nodes <= 2^32 - 256); steady-state scans of
+                                such a graph still run the scan kernel, on 32-bit lists of ids relative to a per-block base */
     uint32_t force_slow;     /* 1 = route every block through the global-memory slow path (tests) */
     uint32_t reserved;       /* low byte 2 = experimental streaming kernel as tier 0; bits 8.. = its grab threshold */
 } bvg_tuning;
