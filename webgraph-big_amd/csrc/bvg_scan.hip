@@ -68,6 +68,19 @@ __device__ __forceinline__ uint32_t task_owner(uint32_t incl, uint32_t t) {
     }
     return lo < 64 ? lo : 63u;
 }
+// The same when only a FEW lanes own tasks (the lists of one level of a sub-row: 4-8): a scalar loop over those lanes -- a v_readlane, a compare
+// and a select each -- instead of six dependent trips through the LDS crossbar.  `m` = lanes that own tasks, `first` = the tasks of the
+// lanes before this one (exclusive prefix); task t belongs to the last such lane whose first task is <= t.
+__device__ __forceinline__ uint32_t deal_few(uint64_t m, uint32_t incl, uint32_t first, uint32_t t) {
+    if (__popcll(m) > 12) return task_owner(incl, t);
+    uint32_t own = threadIdx.x;
+    while (m) {
+        const uint32_t j = (uint32_t)__ffsll((unsigned long long)m) - 1u; m &= m - 1ull;
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)first, (int)j);
+        own = t >= f ? j : own;
+    }
+    return own;
+}
 // gamma from the LDS window: codes of up to 31 bits (values below 2^15: every copy block and interval of a list that fits LDS) from one
 // 32-bit window; the 64-bit decoder only where a lane needs it.  Returns the length, 0 = does not fit.
 __device__ __forceinline__ uint32_t gamma_at(const uint32_t* stage, uint32_t rel, uint64_t& v) {
@@ -685,7 +698,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     for (uint32_t p0 = 0; p0 < Itot; p0 += 64) {
                         const bool tl = p0 + lane < Itot;
                         BVG_WC(3, 1);
-                        const uint32_t own = task_owner(iincl2, p0 + lane);       // (every lane takes part in the shuffles)
+                        const uint32_t own = deal_few(ballot(In != 0), iincl2, is, p0 + lane);
                         const int nl = tl ? (int)own : (int)lane;
                         const uint32_t s_first = (uint32_t)__shfl((int)is, nl, 64);
                         const uint32_t q = tl ? p0 + lane - s_first : 0u;
@@ -758,7 +771,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
                     const uint32_t tq2 = BVG_T0();
                     const bool tl = p0 + lane < Ttot;                     // task of this lane: (node lane, task index inside the node)
                     BVG_WC(1, 1); BVG_WCL(2, tl ? 1u : 0u);
-                    const uint32_t own = task_owner(tincl, p0 + lane);           // (every lane takes part in the shuffles)
+                    const uint32_t own = deal_few(ballot(Tn != 0), tincl, ts, p0 + lane);
                     const int nl = tl ? (int)own : (int)lane;
                     const uint32_t s_first = (uint32_t)__shfl((int)ts, nl, 64);
                     const uint32_t q = tl ? p0 + lane - s_first : 0u;
