@@ -131,9 +131,12 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
     const int64_t rep_lo = s > a.from ? s : a.from, rep_hi = e < a.to ? e : a.to;
 
     T* const pool = reinterpret_cast<T*>(dyn_lds);
-    T* const scr = pool + a.lds_pool_elems;
-    const uint32_t CAP = a.lds_pool_elems, SCR = a.lds_scr_elems;
-    uint32_t* const stage_w = reinterpret_cast<uint32_t*>(scr + SCR);        // the window over the stream: read by every sub-row of a super-row
+    // ONE area for the lists (bottom up), the parked residuals of a sub-row (top down, below the scratch) and the super-row's scratch -- copy
+    // blocks and intervals, at the very top, as large as this super-row needs (a fixed scratch area stood 60 % empty on average): what the
+    // scratch does not take, the sub-rows get.  `scr` indexes the same area; sb / ib are absolute.
+    T* const scr = pool;
+    const uint32_t CAP = a.lds_pool_elems + a.lds_scr_elems;
+    uint32_t* const stage_w = reinterpret_cast<uint32_t*>(pool + CAP);       // the window over the stream: read by every sub-row of a super-row
     const uint32_t* const stage = stage_w;
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
@@ -297,12 +300,13 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             }
         }
         // the copy blocks and intervals of the super-row go to the scratch area
-        const uint32_t SCRH = SCR;
+        const uint32_t SCRH = (CAP - pool_used) >> 1;                         // at most half of what the lists carried over leave free
         const uint32_t bincl = wave_incl_scan32(bc > SCRH ? SCRH + 1 : bc);
         { const uint32_t kb = (uint32_t)__popcll(ballot(bincl <= SCRH)); K1 = kb < K1 ? kb : K1; }
         if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF3u; break; }       // one node's copy blocks exceed the scratch area
-        sb = bincl - bc;
-        uint32_t btot = lane_get(bincl, K1 - 1);
+        const uint32_t btot = lane_get(bincl, K1 - 1);                        // (stays, should the intervals cut the super-row shorter: the blocks are written by then)
+        const uint32_t bbase = CAP - btot;
+        sb = bbase + bincl - bc;
         // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
         uint32_t rlenN = 0;
 #if defined(BVG_PROF) && defined(BVG_PROF_WORK)
@@ -365,10 +369,12 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         for (;;) {
             const uint32_t ki = (uint32_t)__popcll(ballot(btot + iincl <= SCRH));
             if (ki != 0 || K1 <= 1) { K1 = ki < K1 ? ki : K1; break; }
-            K1 = (K1 + 1u) >> 1; btot = lane_get(bincl, K1 - 1);
+            K1 = (K1 + 1u) >> 1;
         }
         if (K1 == 0) { failed = true; fail_need = 0xFFFFFFF4u; break; }       // one node's intervals exceed the scratch area
-        ib = btot + iincl - iw;
+        const uint32_t itot = lane_get(iincl, K1 - 1);
+        const uint32_t CAPe = bbase - itot;                                   // what is left for the lists and the parked residuals of this super-row's sub-rows
+        ib = CAPe + iincl - iw;
         parse = parse && lane < K1;
         // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals
         if (parse) {
@@ -497,7 +503,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
         uint32_t sa = 0;
         while (sa < K1) {
             const uint32_t tq8b = BVG_T0();
-            const uint32_t avail = CAP - pool_used;
+            const uint32_t avail = CAPe - pool_used;
             const bool cand = on1 && lane >= sa;
             const uint32_t size = (cand && stored) ? dclamp : 0u;
             const uint32_t rsz = (cand && stored && !direct) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
@@ -515,7 +521,7 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
             const bool act = cand && lane < se;
             const bool rep = act && repn;
             const uint32_t base = pool_used + (sincl - size);
-            const uint32_t rtb = CAP - (rincl > CAP ? CAP : rincl);
+            const uint32_t rtb = CAPe - (rincl > CAPe ? CAPe : rincl);
             if (act) nd_base[(uint32_t)x & RM] = (uint16_t)(stored ? base : kNoList);        // (a leaf has no list: nothing to compact, nothing to copy from)
             pool_used += lane_get(sincl, se - 1);
             BVG_T1(8, tq8b);
