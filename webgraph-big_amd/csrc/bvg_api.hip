@@ -615,20 +615,26 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
                 // queue) + static arrays.  Resident wavefronts per CU step down with it; take the largest even count whose pool
                 // still holds a row's worth of lists (leaves take no pool: about half the row kernel's need).
-                const uint32_t stagew = knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, 512);   // a super-row: the records that fit it, up to 64 (profiles/r03_ab_cfg.txt, r03_ab_stage.txt)
-                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 448;     // copy blocks + intervals of 64 nodes, run queue of a sub-row
-                const uint64_t lds_cu = 160 * 1024, fixed = scan_static_lds() + 64 + (uint64_t)stagew * 4 + scrw * 4;
-                auto foot = [&](uint64_t pe) { return (pe * 4 + fixed + 127) & ~127ull; };
+                // The window: 512 dwords at up to 14 wavefronts, 384 at 16 (profiles/r03_ab_uni.txt; a super-row = the records that fit it, up to 64).
+                // Lists, parked residuals and the super-row's copy blocks / intervals share pool + scratch (bvg_scan.hip): about half the
+                // scratch is free for lists on average, and counts as such here.
+                const uint64_t scrw = knob("BVG_SCAN_SCR") ? strtoull(knob("BVG_SCAN_SCR"), nullptr, 10) : 448;
+                const uint64_t lds_cu = 160 * 1024;
+                auto stage_of = [&](uint64_t w) -> uint32_t {
+                    return knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, w >= 16 ? 384 : 512);
+                };
+                auto foot = [&](uint64_t pe, uint64_t w) { return (pe * 4 + scan_static_lds() + 64 + (uint64_t)stage_of(w) * 4 + scrw * 4 + 127) & ~127ull; };
                 const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 20.0;   // window lists + a sub-row's stored lists and parked residuals
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
                 for (uint64_t w : {16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
                     if (wforce && w != wforce && w != 4) continue;
                     uint64_t pw = 8192;
-                    while (pw > 512 && lds_cu / foot(pw) < w) pw -= 32;
-                    if (lds_cu / foot(pw) >= w && ((double)pw >= lists * avg || w == 4 || wforce)) { pool = pw; waves = lds_cu / foot(pw); break; }
+                    while (pw > 512 && lds_cu / foot(pw, w) < w) pw -= 32;
+                    if (lds_cu / foot(pw, w) >= w && ((double)(pw + scrw / 2) >= lists * avg || w == 4 || wforce)) { pool = pw; waves = w; break; }
                 }
-                while (pool + 32 <= 8192 && lds_cu / foot(pool + 32) == waves) pool += 32;
+                const uint32_t stagew = stage_of(waves);
+                while (pool + 32 <= 8192 && lds_cu / foot(pool + 32, waves) >= waves) pool += 32;
                 if (knob("BVG_SCAN_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(knob("BVG_SCAN_POOL"), nullptr, 10), 512), 12288);
                 af.lds_pool_elems = (uint32_t)pool; af.lds_scr_elems = (uint32_t)scrw;
                 af.lds_stage_words = stagew;
@@ -658,7 +664,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     const bool fastb = fast_ok && skx->h_fmt[lo + i] == 1 && pd.leanfail[lo + i] < 2;   // (a block the lean kernel failed twice -- first for its pool, then in the class it was sent to -- stays on the row kernel)
                     int c;
                     if (long_record) c = 5;
-                    else if (fastb ? (md / 2 + 64 <= af.lds_pool_elems) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
+                    else if (fastb ? (md / 2 + 64 <= af.lds_pool_elems + af.lds_scr_elems / 2) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
                     else { c = 1; while (c < 5 && (fastb ? lclasses : classes)[c - 1] < need) c++; }
                     int lrn = pd.learned[lo + i];                              // learned from an earlier scan's cascade -- in classes of the ROW kernel, whose
                     if (fastb && wide && lrn) lrn = std::max(1, lrn - 1);       // 64-bit lists take twice the bytes: the lean class one below holds as many elements
