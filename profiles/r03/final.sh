@@ -35,5 +35,5 @@ export BVG_TEST_KNOBS=1
 out=gpurun_out/r03_section_timers.txt; echo "== libbvgraph_hip_prof.so, BVG_DBG=64, 1 GiB of the eu15 mosaic, one steady-state scan; M wave-cycles per section of scan_kernel (slots of the row kernel's report: 'row prep' = levels, 'task set-up' = Z2 set-up, 'seeks' = Z1, 'merge loop' = Z2 loop)" > $out
 BVG_HIP_LIB=$PWD/webgraph-big_amd/lib/libbvgraph_hip_prof.so BVG_DEBUG=1 BVG_DBG=64 timeout -k 10 300 python bench.py --steps 1 --warmup 1 --target-gib 1 --no-cpu-baseline --no-verify 2>&1 | grep -E "wave-cycles|phase 1 split|tiers concurrent|scan kernel" | tail -5 | cut -c1-300 >> $out
 cat $out
-# occupancy: the same pool (the 14-wavefront configuration), unused LDS added so that fewer wavefronts fit a CU
-TAG=occ14 CONFIGS="BVG_SCAN_WAVES=14;BVG_SCAN_WAVES=14 BVG_SCAN_PAD=1700;BVG_SCAN_WAVES=14 BVG_SCAN_PAD=4600;BVG_SCAN_WAVES=14 BVG_SCAN_PAD=8800;BVG_SCAN_WAVES=14 BVG_SCAN_PAD=15400" bash profiles/r03/ab.sh | cut -c1-200
+# occupancy: the same pool (the default 16-wavefront configuration), unused LDS added so that fewer wavefronts fit a CU
+TAG=occ16 CONFIGS="BVG_SCAN_WAVES=16;BVG_SCAN_WAVES=16 BVG_SCAN_PAD=1400;BVG_SCAN_WAVES=16 BVG_SCAN_PAD=3400;BVG_SCAN_WAVES=16 BVG_SCAN_PAD=6100;BVG_SCAN_WAVES=16 BVG_SCAN_PAD=10200;BVG_SCAN_WAVES=16 BVG_SCAN_PAD=17000" bash profiles/r03/ab.sh | cut -c1-200

@@ -9,7 +9,8 @@
 //     references of the super-row are then known (and those of the next one's first W records are peeked at), so exactly the lists
 //     that some later node copies from are STORED; every other node is a LEAF.  The lists are built in sub-rows of as many nodes as the
 //     pool holds next to the stored lists of the W nodes before them -- so the LDS footprint follows the pool, not the 64-record
-//     parse, and 14 wavefronts fit a CU where the row kernel holds 8;
+//     parse, and 16 wavefronts fit a CU where the row kernel holds 8.  Lists (bottom up), the parked residuals of a sub-row (top down)
+//     and the super-row's copy blocks and intervals (at the very top, exactly as many as it has) share ONE area;
 //   * the three streams of a record are disjoint (BVG:1062-1090 merges them; a stream where they overlap failed validation and stays
 //     on the checking kernels), so nothing has to be located to be COUNTED: every residual is folded into the checksum the moment it is
 //     decoded, and a leaf (~60 % of the nodes of a web graph) is never materialised, never positioned, its residuals never parked;
@@ -25,7 +26,7 @@
 //     when they lie in it, else from 12 bytes fetched from memory while the intervals are parsed;
 //   * flat tasks (residual segments, extras, position tasks, chunks) are dealt to lanes by a binary search over the prefix sums of the
 //     task counts with six shuffles (task_owner) -- no task maps in LDS, no loop over a lane's tasks.
-// At 14 wavefronts per CU the kernel is bound by vector-instruction issue (profiles/r03_eu15_pmc_summary.txt, r03_ab_dummy.txt: an
+// At 14-16 wavefronts per CU the kernel is bound by vector-instruction issue (profiles/r03_eu15_pmc_summary.txt, r03_ab_dummy.txt: an
 // added VALU instruction costs exactly its issue time): hiding more latency (prefetching the next window or the skip entries into
 // registers, 16 wavefronts with the pool they leave) does not move it; fewer instructions per arc do.
 // Builds for measuring: -DBVG_PROF (wave-cycles per section), -DBVG_PROF -DBVG_PROF_WORK (`make work`: passes / steps / elements of
