@@ -115,8 +115,10 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
 }
 
 // NBZ: the node base is 0 (no carry handling in the checksum key); Z3: zeta_3 residuals (the specialised decoder)
-template <bool NBZ, bool Z3, bool WIDE>
-__global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) {
+// OCC: wavefronts per SIMD the register allocation leaves room for -- 4 (128 VGPRs: nothing spills, 16 wavefronts per CU) or 6 (85 VGPRs, a
+// handful of spills, 24 per CU: sparse graphs, whose lists need little LDS, gain 9 % from the extra wavefronts; profiles/r03_ab_w20.txt)
+template <bool NBZ, bool Z3, bool WIDE, int OCC>
+__global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
     __shared__ uint16_t nd_d[kRing];              // outdegree, clamped (a list longer than the pool fails the block before anything copies from it)
@@ -963,14 +965,18 @@ __global__ void __launch_bounds__(64, BVG_SCAN_WAVES) scan_kernel(DecodeArgs a) 
 // what the kernel needs of LDS besides the pool and the scratch area (static arrays)
 size_t scan_static_lds() { return (size_t)kRing * 4; }
 
-void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, hipStream_t s) {
+template <int OCC> static void launch_scan_occ(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
+    const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, OCC>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, OCC>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); }
+}
+
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, hipStream_t s) {
     if (nblocks == 0) return;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
-    const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
-    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    if (many_waves) launch_scan_occ<6>(a, nblocks, wide, dyn, s); else launch_scan_occ<4>(a, nblocks, wide, dyn, s);
 }
 
 }  // namespace bvg
