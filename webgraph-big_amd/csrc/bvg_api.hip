@@ -275,6 +275,28 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
     for (size_t i = 0; i < first.size(); i++) if (uniq.empty() || first[i] != uniq.back()) uniq.push_back(first[i]);
     if (uniq.back() != (uint64_t)n) uniq.push_back((uint64_t)n);
     uint32_t nblk = (uint32_t)(uniq.size() - 1);
+    // A record longer than the LDS stream window sends its whole block to the giant kernel, which walks a block node by node with the
+    // whole workgroup: the ~50 ordinary nodes that share the block with it cost that kernel more than the long record itself (4.4 G-node
+    // run: 157 k such blocks = 2.0 s of a scan whose tier 0 ends after 1.2 s).  Cut the block in front of the long record (it is the
+    // block's last node or nearly: the record runs past the block's end), so that the nodes before it stay with the LDS kernels.
+    if (!knob("BVG_NO_LONGCUT")) {
+        uint64_t *d_f = nullptr, *d_node = nullptr, *d_bits = nullptr;
+        HIPCHK(hipMalloc(&d_f, (nblk + 1) * sizeof(uint64_t))); HIPCHK(hipMalloc(&d_node, (size_t)nblk * sizeof(uint64_t))); HIPCHK(hipMalloc(&d_bits, (size_t)nblk * sizeof(uint64_t)));
+        HIPCHK(hipMemcpyAsync(d_f, uniq.data(), (nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g->stream));
+        launch_plan_longest(sh->offs, d_f, nblk, d_node, d_bits, g->stream);
+        std::vector<uint64_t> hn(nblk), hb(nblk);
+        HIPCHK(hipMemcpyAsync(hn.data(), d_node, (size_t)nblk * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipMemcpyAsync(hb.data(), d_bits, (size_t)nblk * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        (void)hipFree(d_f); (void)hipFree(d_node); (void)hipFree(d_bits);
+        std::vector<uint64_t> cut; cut.reserve(uniq.size() + 1024);
+        for (uint32_t k = 0; k < nblk; k++) {
+            cut.push_back(uniq[k]);
+            if (hb[k] + 128 > 32768 && hn[k] > uniq[k] && hn[k] < uniq[k + 1]) cut.push_back(hn[k]);
+        }
+        cut.push_back(uniq[nblk]);
+        if (cut.size() - 1 <= 0x7FFFFFF0ull) { uniq.swap(cut); nblk = (uint32_t)(uniq.size() - 1); }
+    }
     // halo per boundary; boundaries whose reference chains reach further back than kMaxHalo nodes are removed
     for (int pass = 0; pass < 2; pass++) {
         uint64_t* d_first = nullptr; uint32_t* d_halo = nullptr; uint64_t* d_mask = nullptr;

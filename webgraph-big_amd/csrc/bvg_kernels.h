@@ -151,6 +151,7 @@ void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, Offsets offsets
                       int window, Codings cod, uint32_t* halo, uint64_t* mask, hipStream_t s);
 
 // plan: largest outdegree among the nodes a block decodes (its own + its halo): predicts the LDS tier it needs
+void launch_plan_longest(Offsets offsets, const uint64_t* first, uint32_t nblk, uint64_t* node, uint64_t* bits, hipStream_t s);
 void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
                       int outdegree_coding, int window, uint32_t* maxd, hipStream_t s);
 

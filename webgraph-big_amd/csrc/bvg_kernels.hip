@@ -640,6 +640,29 @@ void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, Offsets offsets
     hipLaunchKernelGGL(plan_halo_kernel, dim3((nblk + 127) / 128), dim3(128), 0, s, graph, limit_byte, offsets, n, first, nblk, window, cod, halo, mask);
 }
 
+// the longest record of every block: its node and its length in bits (one wavefront per block)
+__global__ void plan_longest_kernel(Offsets offsets, const uint64_t* first, uint32_t nblk, uint64_t* node, uint64_t* bits) {
+    const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= nblk) return;
+    const unsigned lane = threadIdx.x & 63u;
+    uint64_t best = 0, at = first[k];
+    for (uint64_t x = first[k] + lane; x < first[k + 1]; x += 64) {
+        const uint64_t len = offsets[(int64_t)x + 1] - offsets[(int64_t)x];
+        if (len > best) { best = len; at = x; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t b2 = __shfl_xor(best, o, 64), a2 = __shfl_xor(at, o, 64);
+        if (b2 > best || (b2 == best && a2 < at)) { best = b2; at = a2; }
+    }
+    if (lane == 0) { node[k] = at; bits[k] = best; }
+}
+
+void launch_plan_longest(Offsets offsets, const uint64_t* first, uint32_t nblk, uint64_t* node, uint64_t* bits, hipStream_t s) {
+    if (!nblk) return;
+    hipLaunchKernelGGL(plan_longest_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, offsets, first, nblk, node, bits);
+}
+
 void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
                       int coding, int window, uint32_t* maxd, hipStream_t s) {
     if (!nblk) return;
