@@ -620,7 +620,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             r = upload_work(); if (r) return r;
             work.clear();
         }
-        const uint32_t max_pool = wide ? 6144 : 12288;
+        const uint32_t max_pool = 12288;                              // (elements, whatever their width: 127 KB of LDS for the largest class of the 64-bit row kernel -- it is what VALIDATES such a block for the scan kernel, whose lists are 32-bit on every graph)
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
         const uint32_t lclasses[4] = {2048, 4096, 8192, 12288};               // the lean scan kernel's lists are 32-bit on every graph (block-relative ids beyond 2^32 nodes)
         const bool predict = !batch && !stream && !legacy && pl.h_maxd.size() == pl.nblk && !knob("BVG_NOPREDICT");
@@ -679,7 +679,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (rekey) pd.dirty = false;
             if (rekey || pd.dirty) {
                 std::vector<uint32_t> L[12];                                     // tier 0, four LDS classes, giants (5), the generic kernel (6); 7..11: tier 0 and the classes of the lean scan kernel
-                uint64_t gneed = 0;
+                uint64_t gneed = 0, gnodes = 0, glong = 0;
                 for (uint32_t i = 0; i < nblocks; i++) {
                     const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
                     const bool long_record = (pl.h_maxd[lo + i] >> 31) != 0;
@@ -689,13 +689,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     if (long_record) c = 5;
                     else if (fastb ? (md / 2 + 64 <= af.lds_pool_elems + af.lds_scr_elems / 2) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
                     else { c = 1; while (c < 5 && (fastb ? lclasses : classes)[c - 1] < need) c++; }
-                    int lrn = pd.learned[lo + i];                              // learned from an earlier scan's cascade -- in classes of the ROW kernel, whose
-                    if (fastb && wide && lrn) lrn = std::max(1, lrn - 1);       // 64-bit lists take twice the bytes: the lean class one below holds as many elements
+                    const int lrn = pd.learned[lo + i];                        // learned from an earlier scan's cascade
                     if (lrn > c) { c = lrn; if (c >= 5 && gneed < 65536) gneed = 65536; }
                     if (c == 5 && !giant_ok) c = 6;
                     if (c >= 5 && need > gneed) gneed = need;
+                    if (c >= 5) { gnodes += pl.h_first[lo + i + 1] - pl.h_first[lo + i]; if (long_record) glong++; }
                     L[(fastb && c <= 4) ? 7 + c : c].push_back(lo + i);
                 }
+                if (dbg_on() && L[5].size() + L[6].size()) fprintf(stderr, "[bvg] giant blocks: %zu (%llu of them for a record longer than the window), %llu nodes in them\n", L[5].size() + L[6].size(), (unsigned long long)glong, (unsigned long long)gnodes);
                 pd.dirty = false; pd.mode = pmode;
                 if (pd.d_lists) { (void)hipFree(pd.d_lists); pd.d_lists = nullptr; }
                 HIPCHK(hipMalloc(&pd.d_lists, (size_t)nblocks * sizeof(uint32_t)));
@@ -815,7 +816,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     if (!work.empty() && !force_slow && !force_giant) {
         std::vector<uint32_t> need(work.size());
         HIPCHK(hipMemcpy(need.data(), g->d_fail + 1 + g->fail_cap, work.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        const uint32_t max_pool = wide ? 6144 : 12288;
+        const uint32_t max_pool = 12288;                              // (elements, whatever their width: 127 KB of LDS for the largest class of the 64-bit row kernel -- it is what VALIDATES such a block for the scan kernel, whose lists are 32-bit on every graph)
         const uint32_t classes[4] = {max_pool / 6, max_pool / 3, (max_pool * 2) / 3, max_pool};
         std::vector<uint32_t> bins[4], rest;
         if (dbg_on()) { size_t h[8] = {0}; for (uint32_t nd : need) h[nd >= 0xFFFFFFF0u ? (nd & 7) : 0]++; fprintf(stderr, "[bvg] failures: pool %zu, window %zu, huge %zu, blocks-scratch %zu, intervals-scratch %zu, code %zu, other %zu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[7]); }
