@@ -117,7 +117,7 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
 // NBZ: the node base is 0 (no carry handling in the checksum key); Z3: zeta_3 residuals (the specialised decoder)
 // OCC: wavefronts per SIMD the register allocation leaves room for -- 4 (128 VGPRs: nothing spills, 16 wavefronts per CU) or 6 (85 VGPRs, a
 // handful of spills, 24 per CU: sparse graphs, whose lists need little LDS, gain 9 % from the extra wavefronts; profiles/r03_ab_w20.txt)
-template <bool NBZ, bool Z3, bool WIDE, int OCC>
+template <bool NBZ, bool Z3, bool WIDE, int OCC, bool D2>
 __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
@@ -488,7 +488,20 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 #else
         const bool direct = stored && ref == 0 && ic == 0;
 #endif
-        const uint32_t k1d = (stored && ref == 0 && !direct) ? 0u : k1;
+        // ... and with intervals (28 % of the stored lists, 37 % of the positions the position tasks used to fill): the residuals still go
+        // straight to their places -- each one shifted by the intervals that lie below it, which a task learns as it passes them -- and
+        // whoever passes an interval records where it starts; the intervals themselves are filled in by the extras pass of level 0.
+        // (not in the 85-VGPR instantiation: its state would spill, and sparse graphs hold few intervals; on1: `stored` is set for lanes
+        // behind the super-row too when the peek is unknown)
+        const bool d2 = D2 && OCC == 4 && on1 && stored && ref == 0 && ic != 0;
+        if (ballot(d2)) {                                                      // default start of interval k: behind every residual and the intervals before it
+            if (d2) {
+                uint32_t pre = nres;
+                for (uint32_t kk = 0; kk < ic; kk++) { const uint32_t ln = (uint32_t)scr[ib + 2 * kk + 1] & 0xFFFFu; scr[ib + 2 * kk + 1] = (T)(ln | (pre << 16)); pre += ln; }
+            }
+            wave_sync();
+        }
+        const uint32_t k1d = (stored && ref == 0 && !direct && !d2) ? 0u : k1;
         // skip entries of the super-row, in node order
         const uint32_t cntE = (parse && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
         uint32_t efirst;
@@ -509,7 +522,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             const uint32_t avail = CAPe - pool_used;
             const bool cand = on1 && lane >= sa;
             const uint32_t size = (cand && stored) ? dclamp : 0u;
-            const uint32_t rsz = (cand && stored && !direct) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
+            const uint32_t rsz = (cand && stored && !direct && !d2) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
             const uint32_t sincl = wave_incl_scan32(size), rincl = wave_incl_scan32(rsz);
             const bool fits = lane >= sa && lane < K1 && (uint64_t)sincl + rincl <= avail;
             const uint32_t se = sa + (uint32_t)__popcll(ballot(fits));          // (the sums are prefixes: `fits` is a contiguous run from sa)
@@ -555,6 +568,8 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     BVG_WC(6, 1);
                     const uint32_t tq9p = BVG_T0();
                     bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
+                    uint32_t ivl[RU], ivn[RU], ivk[RU], ioff[RU], tic2[RU], tib2[RU], t0a[RU];   // lists decoded in place around their intervals (d2)
+                    const bool anyd2 = D2 && OCC == 4 && ballot(d2 && act) != 0;
 #pragma unroll
                     for (uint32_t u = 0; u < RU; u++) {
                         const uint32_t t = p0 + 64u * u + lane;
@@ -567,7 +582,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64), s_ce = (uint32_t)__shfl((int)ce, nl, 64);
                         const uint32_t q = tl[u] ? (isl ? t - s_ts : s_ce) : 0u;
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
-                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? (direct ? base : rtb) : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
+                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? ((direct || d2) ? base : rtb) : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
                         tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
                         const uint32_t t0 = q * kSkipEvery;
@@ -584,6 +599,15 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                                 r[u] = (T)sv; if (sv >> 32) { tbad = true; cnt[u] = 0; }
                             } else r[u] = reinterpret_cast<const T*>(a.skip_val)[ei];
                             if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
+                        }
+                        ivl[u] = kInf; ivn[u] = 0; ivk[u] = 0; ioff[u] = 0; tic2[u] = 0; tib2[u] = 0; t0a[u] = t0;
+                        if (anyd2) {                                          // (wave-uniform: the shuffles are executed by every lane)
+                            const uint32_t s_d2 = (uint32_t)__shfl((int)(d2 ? 1 : 0), nl, 64), s_ic = __shfl(ic, nl, 64), s_ib = __shfl(ib, nl, 64);
+                            if (tl[u] && s_d2 && cnt[u]) {
+                                tic2[u] = s_ic; tib2[u] = s_ib;
+                                if (q) while (ivk[u] < s_ic && scr[s_ib + 2 * ivk[u]] < r[u]) { ioff[u] += (uint32_t)scr[s_ib + 2 * ivk[u] + 1] & 0xFFFFu; ivk[u]++; }   // the intervals the tasks before this one have passed
+                                if (ivk[u] < s_ic) { ivl[u] = (uint32_t)scr[s_ib + 2 * ivk[u]]; ivn[u] = (uint32_t)scr[s_ib + 2 * ivk[u] + 1] & 0xFFFFu; }
+                            }
                         }
                     }
                     BVG_T1(14, tq9p);
@@ -627,7 +651,14 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                                 tbad |= on[u] && (((uint64_t)tv) >> 32) != 0;
                             }
                             const uint32_t tn = trel[u] + len[u];
-                            if (on[u] && taddr[u] != kInf) pool[taddr[u] + i] = rn;
+                            if (anyd2 && ballot(on[u] && (uint32_t)rn > ivl[u])) {   // this residual passes an interval (or several): it starts right here
+                                while (on[u] && (uint32_t)rn > ivl[u]) {
+                                    scr[tib2[u] + 2 * ivk[u] + 1] = (T)(ivn[u] | ((t0a[u] + i + ioff[u]) << 16));
+                                    ioff[u] += ivn[u]; ivk[u]++;
+                                    if (ivk[u] < tic2[u]) { ivl[u] = (uint32_t)scr[tib2[u] + 2 * ivk[u]]; ivn[u] = (uint32_t)scr[tib2[u] + 2 * ivk[u] + 1] & 0xFFFFu; } else ivl[u] = kInf;
+                                }
+                            }
+                            if (on[u] && taddr[u] != kInf) pool[taddr[u] + i + ioff[u]] = rn;
                             csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
                             r[u] = rn; trel[u] = on[u] ? tn : trel[u];              // (a lane past its task keeps adding to r: nobody reads it)
                         }
@@ -642,6 +673,8 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 if (nres > 0) {
                     T r = (T)(x - B);
                     uint32_t rr = rel;
+                    uint32_t jk = 0, joff = 0, jl = kInf, jn = 0;                     // (d2: the next interval, what the passed ones add)
+                    if (d2) { jl = (uint32_t)scr[ib]; jn = (uint32_t)scr[ib + 1] & 0xFFFFu; }
                     for (uint32_t t = 0; t < nres; t++) {
                         uint64_t val;
                         const uint32_t len = read_residual<false>(stage, rr, zfast, zk, a.cod.residual, val);
@@ -652,7 +685,11 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                             if (((uint64_t)tv) >> 32) { bad = true; break; }
                         }
                         r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
-                        if (stored) pool[(direct ? base : rtb) + t] = r;
+                        while (d2 && (uint32_t)r > jl) {
+                            scr[ib + 2 * jk + 1] = (T)(jn | ((t + joff) << 16)); joff += jn; jk++;
+                            if (jk < ic) { jl = (uint32_t)scr[ib + 2 * jk]; jn = (uint32_t)scr[ib + 2 * jk + 1] & 0xFFFFu; } else jl = kInf;
+                        }
+                        if (stored) pool[((direct || d2) ? base : rtb) + t + joff] = r;
                         csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
                         if (rr > pend) { bad = true; break; }
                     }
@@ -686,20 +723,23 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 const bool ch = nl != lvl; lvl = nl;
                 if (!ballot(ch)) break;
             }
-            const bool emits = emitn && stored && !direct;
+            const bool emits = emitn && stored && !direct && !d2;
+            const bool fills = act && d2;                                     // their intervals are written by the extras pass of level 0
             if (emits) pool[rtb + nres] = sentinel<T>();                      // guard behind the node's residual positions
-            uint64_t remaining = ballot(emits);
+            uint64_t remaining = ballot(emits || fills);
             wave_sync();
             BVG_T1(0, tq0);
             for (uint32_t L = 0; remaining; L++) {
-                const bool mem = emits && lvl == L;
-                remaining &= ~ballot(mem);
-                if (!ballot(mem)) continue;
+                const bool mem = emits && lvl == L, memf = fills && L == 0;
+                remaining &= ~ballot(mem || memf);
+                if (!ballot(mem || memf)) continue;
                 BVG_WC(0, 1);
                 // ---------------- Z1: one lane per extra: its output position = (extras below it) + (copied elements below it)
                 const uint32_t tq3 = BVG_T0();
                 {
-                    const uint32_t In = mem ? nresN + ic : 0u;
+                    const uint32_t In = mem ? nresN + ic : (memf ? ic : 0u);
+                    const bool anyf = ballot(memf) != 0;
+                    uint64_t fsum = 0;
                     const uint32_t iincl2 = wave_incl_scan32(In), is = iincl2 - In, Itot = lane_get(iincl2, 63);
 #ifdef BVG_ABLATE_Z1
                     if (false)
@@ -715,8 +755,18 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                         const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                         const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
-                        T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false;
-                        if (tl) {
+                        T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false, isfill = false;
+                        uint32_t f_k0 = 0, f_k1 = 0;
+                        if (anyf) {                                           // (wave-uniform: the shuffles are executed by every lane)
+                            const int s_f = __shfl((int)(memf ? 1 : 0), nl, 64);      // (hoisted: `tl && __shfl()` would run the shuffle under a lane mask)
+                            isfill = tl && s_f != 0;
+                            f_k0 = __shfl(k0, nl, 64); f_k1 = __shfl(k1, nl, 64);
+                        }
+                        if (isfill) {                                         // an interval of a list decoded in place: its start was recorded when the residuals passed it
+                            vv = scr[t_ib + 2 * q]; const T pk = scr[t_ib + 2 * q + 1];
+                            len = (uint32_t)(pk & HM); pe = (uint32_t)(pk >> HS);
+                            if (pe + len > t_d) { pe = 0; len = 0; }
+                        } else if (tl) {
                             uint32_t eb;
                             if (q < t_ic) {                                   // interval q: the intervals and residuals below it
                                 isiv = true;
@@ -743,11 +793,13 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                         wave_sync();                                      // the parked values have been read: positions may replace them
                         if (tl && len) {
-                            if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
+                            if (isfill) { for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); fsum += mix_node<T>(f_k0, f_k1, (T)(vv + i), nb_lo, nbz); } }
+                            else if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
                             else { pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
                         }
                         wave_sync();
                     }
+                    blk_chk += fsum;
                 }
                 BVG_T1(3, tq3);
                 const uint32_t tq1 = BVG_T0();
@@ -965,18 +1017,22 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 // what the kernel needs of LDS besides the pool and the scratch area (static arrays)
 size_t scan_static_lds() { return (size_t)kRing * 4; }
 
-template <int OCC> static void launch_scan_occ(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
+template <int OCC, bool D2> static void launch_scan_occ(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
     const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
-    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, OCC>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, OCC>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, OCC>), dim3(nblocks), dim3(64), dyn, s, a); }
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, hipStream_t s) {
     if (nblocks == 0) return;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
-    if (many_waves) launch_scan_occ<6>(a, nblocks, wide, dyn, s); else launch_scan_occ<4>(a, nblocks, wide, dyn, s);
+    // D2 (lists without reference decoded in place around their intervals): only where such lists exist and are copied from
+    const bool d2 = a.min_interval != 0 && a.window > 0 && !(knob("BVG_NO_D2") && atoi(knob("BVG_NO_D2")));
+    if (many_waves) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
+    else if (d2) launch_scan_occ<4, true>(a, nblocks, wide, dyn, s);
+    else launch_scan_occ<4, false>(a, nblocks, wide, dyn, s);
 }
 
 }  // namespace bvg
