@@ -220,3 +220,53 @@ def test_wide_graphs_take_the_scan_kernel_with_block_relative_ids(W, tools, orac
         ra, oa = g.scan(a, b), og.scan(a, b)
         assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (half, a, b)
     g.close()
+
+
+def test_reference_free_lists_with_intervals_decoded_in_place(W, oracle):
+    """Hand-assembled records again: every third node holds a list without reference made of residuals AND intervals (BVGraph.java:1042-1058)
+    -- before, between and behind the residuals, adjacent ones, lists that are one interval only, lists long enough for skip entries --
+    and the two nodes after it copy from it.  The scan kernel decodes the residuals of such a stored list straight into their places,
+    shifted by the intervals they pass, and fills the intervals in where the residuals passed them (LongIntervalSequenceIterator.java:57-78)."""
+    rng = np.random.default_rng(99)
+    n = 6000
+    recs, lists = [], []
+    for x in range(n):
+        lo, hi = max(0, x - 3000), min(n, x + 3000)
+        if x % 3 == 0:
+            kind = (x // 3) % 5
+            nres = [0, 5, 40, 90, 20][kind]
+            k = [1, 3, 2, 4, 1][kind]                                              # intervals
+            pts = np.sort(rng.choice(np.arange(lo, hi - 40), size=k, replace=False))
+            ivs, taken = [], set()
+            for p in pts:
+                ln = int(rng.integers(4, 30))
+                if any(v in taken for v in range(int(p) - 1, int(p) + ln + 1)): continue   # keep intervals apart (adjacent ones would be one interval)
+                ivs.append((int(p), ln)); taken.update(range(int(p), int(p) + ln))
+            free = np.array([v for v in range(lo, hi) if v not in taken and (v - 1) not in taken and (v + 1) not in taken])
+            res = sorted(int(v) for v in rng.choice(free, size=min(nres, len(free)), replace=False))
+            # residuals must not form runs of 4 or more (the encoder would have made them an interval; a decoder does not care, but stay canonical)
+            l = sorted(set(res) | taken)
+            recs.append(Record(d=len(l), intervals=ivs, residuals=res))
+        else:
+            ref = x % 3
+            base = lists[x - ref]
+            k1 = len(base) // 3
+            blocks, kept = ([k1], base[:k1]) if ref == 1 else ([0, k1], base[k1:])   # a prefix / everything but a prefix
+            extra = sorted(int(v) for v in rng.choice(np.setdiff1d(np.arange(lo, hi), np.array(kept, dtype=np.int64)), size=int(rng.integers(0, 12)), replace=False))
+            l = sorted(kept + extra)
+            recs.append(Record(d=len(l), ref=ref, blocks=blocks, residuals=extra))
+        lists.append(l)
+    gbytes, offs, expect = assemble(recs)
+    assert expect == lists
+    p = W.default_params().clone(nodes=n, arcs=int(sum(len(l) for l in lists)))
+    og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), gbytes, offs)
+    g = W.BVGraph.from_memory(p, np.frombuffer(gbytes, dtype=np.uint8), offs)
+    o = og.scan()
+    for _ in range(3):
+        r = g.scan()
+        assert _same(r, o)
+    assert r["lean_blocks"] >= 0.9 * (r["lean_blocks"] + r["slow_blocks"]), r
+    for a, b in ((1, n - 1), (2000, 2007), (4001, 4003)):
+        ra, oa = g.scan(a, b), og.scan(a, b)
+        assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (a, b)
+    g.close()
