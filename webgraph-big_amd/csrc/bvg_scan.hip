@@ -20,8 +20,10 @@
 //     elements dealt to all 64 lanes; a chunk is straight-line groups of {4 LDS reads in flight, 4 mixes}: no per-element block
 //     bookkeeping, no branch inside a chunk;
 //   * stored lists are built as in the row kernel (emission by output position, level by level; block ends and residual positions
-//     are handled without branches in the position loop) -- except a stored list without reference and without intervals, which IS
-//     its residuals: they are decoded straight into its place (nothing parked, no level, no position task);
+//     are handled without branches in the position loop) -- except a stored list without reference, which is its residuals and its
+//     intervals: the residuals are decoded straight into their places (nothing parked, no level, no position task), each one shifted by
+//     the intervals below it, which a decoding task learns as its values pass their left ends; whoever passes an interval records where
+//     it starts, and the extras pass of level 0 fills the intervals in;
 //   * which of the last W lists of a super-row the NEXT super-row copies from is read off that one's records: from the staged window
 //     when they lie in it, else from 12 bytes fetched from memory while the intervals are parsed;
 //   * flat tasks (residual segments, extras, position tasks, chunks) are dealt to lanes by a binary search over the prefix sums of the
