@@ -338,7 +338,7 @@ def cpu_baseline(sts, bases_gpu, basename, threads, gib):
         ts = T.mosaic_host(sts, k)
         og = O.Graph.from_memory(O.Params(**ts.params.as_dict()), ts.graph.tobytes(), ts.offsets)
         n = ts.params.nodes
-        what = "first %d cycle(s) of the workload (%d tiles" % (k, k * len(sts))
+        what = "first %d cycle(s) of the workload (%d tiles, " % (k, k * len(sts))
         gbytes = len(ts.graph)
     else:
         og = O.Graph.load(basename)
