@@ -297,8 +297,14 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
         cut.push_back(uniq[nblk]);
         if (cut.size() - 1 <= 0x7FFFFFF0ull) { uniq.swap(cut); nblk = (uint32_t)(uniq.size() - 1); }
     }
-    // halo per boundary; boundaries whose reference chains reach further back than kMaxHalo nodes are removed
-    for (int pass = 0; pass < 2; pass++) {
+    // halo per boundary; boundaries whose reference chains reach further back than kMaxHalo nodes are removed.
+    // Two rounds: the first one's per-block list sizes show which blocks owe their LDS class (or the giant kernel) to ONE large list; those
+    // are cut in front of that list and W + 1 nodes behind it, so that only the few nodes around it run at the class's low occupancy and
+    // the rest of the block goes back to tier 0 (the classes held 12 % of the blocks of the default workload and took 28 % of a scan).
+    const bool refine = !knob("BVG_NO_LISTCUT") && sh->p.window_size <= kMaxWindow;
+    for (int round = 0; round < 2; round++) {
+      bool done = false;
+      for (int pass = 0; pass < 2 && !done; pass++) {
         uint64_t* d_first = nullptr; uint32_t* d_halo = nullptr; uint64_t* d_mask = nullptr;
         HIPCHK(hipMalloc(&d_first, (nblk + 1) * sizeof(uint64_t)));
         HIPCHK(hipMalloc(&d_halo, (size_t)nblk * sizeof(uint32_t)));
@@ -312,18 +318,42 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
         for (uint32_t k = 0; k < nblk; k++) if (halo[k] == 0xFFFFFFFFu) { any_bad = true; break; }
         if (!any_bad || pass == 1) {
             if (any_bad) { (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask); return BVG_E_UNSUPPORTED; }
-            plan.d_first = d_first; plan.d_halo = d_halo; plan.d_mask = d_mask;
-            plan.nblk = nblk; plan.h_first = uniq;
-            {   // per-block largest outdegree (one wavefront per block), kept on the host to predict tiers
-                uint32_t* d_maxd = nullptr;
-                HIPCHK(hipMalloc(&d_maxd, (size_t)nblk * sizeof(uint32_t)));
-                launch_plan_maxd(sh->d_graph, limit, sh->offs, d_first, d_halo, nblk, sh->p.outdegree_coding, sh->p.window_size, d_maxd, g->stream);
-                plan.h_maxd.resize(nblk);
-                hipError_t e2 = hipMemcpyAsync(plan.h_maxd.data(), d_maxd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
-                if (e2 == hipSuccess) e2 = hipStreamSynchronize(g->stream);
-                (void)hipFree(d_maxd);
-                if (e2 != hipSuccess) return BVG_E_HIP;
+            // per-block largest "list + window" (one wavefront per block), kept on the host to predict tiers; the block's longest list and its node
+            uint32_t* d_maxd = nullptr; uint64_t* d_bign = nullptr; uint32_t* d_bigd = nullptr;
+            HIPCHK(hipMalloc(&d_maxd, (size_t)nblk * sizeof(uint32_t)));
+            const bool want_cuts = refine && round == 0;
+            if (want_cuts) { HIPCHK(hipMalloc(&d_bign, (size_t)nblk * sizeof(uint64_t))); HIPCHK(hipMalloc(&d_bigd, (size_t)nblk * sizeof(uint32_t))); }
+            launch_plan_maxd(sh->d_graph, limit, sh->offs, d_first, d_halo, nblk, sh->p.outdegree_coding, sh->p.window_size, d_maxd, d_bign, d_bigd, g->stream);
+            std::vector<uint32_t> maxd(nblk), bigd(want_cuts ? nblk : 0); std::vector<uint64_t> bign(want_cuts ? nblk : 0);
+            hipError_t e2 = hipMemcpyAsync(maxd.data(), d_maxd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
+            if (e2 == hipSuccess && want_cuts) e2 = hipMemcpyAsync(bign.data(), d_bign, (size_t)nblk * sizeof(uint64_t), hipMemcpyDeviceToHost, g->stream);
+            if (e2 == hipSuccess && want_cuts) e2 = hipMemcpyAsync(bigd.data(), d_bigd, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost, g->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(g->stream);
+            (void)hipFree(d_maxd); if (d_bign) (void)hipFree(d_bign); if (d_bigd) (void)hipFree(d_bigd);
+            if (e2 != hipSuccess) { (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask); return BVG_E_HIP; }
+            if (want_cuts) {
+                // a block above the tier-0 capacity (about 2 000 elements of "worst list + window" / 2) with one list that is most of it
+                const uint64_t W1 = (uint64_t)sh->p.window_size + 1;
+                std::vector<uint64_t> cut; cut.reserve(uniq.size() + 1024); size_t ncut = 0;
+                for (uint32_t k = 0; k < nblk; k++) {
+                    cut.push_back(uniq[k]);
+                    const uint64_t md = maxd[k] & 0x7FFFFFFFu;
+                    if (md / 2 + 64 > 1800 && bigd[k] >= (knob("BVG_LISTCUT_D") ? (uint32_t)atoi(knob("BVG_LISTCUT_D")) : 800u) && uniq[k + 1] - uniq[k] > 2 * W1 + 8) {
+                        if (bign[k] > uniq[k] + 4) { cut.push_back(bign[k]); ncut++; }
+                        if (bign[k] + W1 + 4 < uniq[k + 1]) { cut.push_back(bign[k] + W1); ncut++; }
+                    }
+                }
+                cut.push_back(uniq[nblk]);
+                if (ncut && cut.size() - 1 <= 0x7FFFFFF0ull) {
+                    if (dbg_on()) fprintf(stderr, "[bvg] plan: %zu cuts around large lists (%u blocks before)\n", ncut, nblk);
+                    (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask);
+                    uniq.swap(cut); nblk = (uint32_t)(uniq.size() - 1);
+                    done = true;                                           // next round on the refined boundaries
+                    continue;
+                }
             }
+            plan.d_first = d_first; plan.d_halo = d_halo; plan.d_mask = d_mask;
+            plan.nblk = nblk; plan.h_first = uniq; plan.h_maxd.swap(maxd);
             plan.version = next_plan_version();
             return publish();
         }
@@ -333,6 +363,8 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
         kept.push_back((uint64_t)n);
         uniq.swap(kept); nblk = (uint32_t)(uniq.size() - 1);
         (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask);
+      }
+      if (!done) break;
     }
     return BVG_E_UNSUPPORTED;
 }
@@ -680,6 +712,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (rekey || pd.dirty) {
                 std::vector<uint32_t> L[12];                                     // tier 0, four LDS classes, giants (5), the generic kernel (6); 7..11: tier 0 and the classes of the lean scan kernel
                 uint64_t gneed = 0, gnodes = 0, glong = 0;
+                const double admit = knob("BVG_ADMIT") ? atof(knob("BVG_ADMIT")) : 0.5;   // share of a block's worst "list + window" that tier 0 of the scan kernel must hold
                 for (uint32_t i = 0; i < nblocks; i++) {
                     const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
                     const bool long_record = (pl.h_maxd[lo + i] >> 31) != 0;
@@ -687,7 +720,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     const bool fastb = fast_ok && skx->h_fmt[lo + i] == 1 && pd.leanfail[lo + i] < 2;   // (a block the lean kernel failed twice -- first for its pool, then in the class it was sent to -- stays on the row kernel)
                     int c;
                     if (long_record) c = 5;
-                    else if (fastb ? (md / 2 + 64 <= af.lds_pool_elems + af.lds_scr_elems / 2) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
+                    else if (fastb ? ((uint64_t)((double)md * admit) + 64 <= af.lds_pool_elems + af.lds_scr_elems / 2) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
                     else { c = 1; while (c < 5 && (fastb ? lclasses : classes)[c - 1] < need) c++; }
                     const int lrn = pd.learned[lo + i];                        // learned from an earlier scan's cascade
                     if (lrn > c) { c = lrn; if (c >= 5 && gneed < 65536) gneed = 65536; }

@@ -153,7 +153,7 @@ void launch_plan_halo(const uint8_t* graph, uint64_t limit_byte, Offsets offsets
 // plan: largest outdegree among the nodes a block decodes (its own + its halo): predicts the LDS tier it needs
 void launch_plan_longest(Offsets offsets, const uint64_t* first, uint32_t nblk, uint64_t* node, uint64_t* bits, hipStream_t s);
 void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
-                      int outdegree_coding, int window, uint32_t* maxd, hipStream_t s);
+                      int outdegree_coding, int window, uint32_t* maxd, uint64_t* bign, uint32_t* bigd, hipStream_t s);
 
 // offsets index from a bare .graph (BVGraph -O / writeOffsets, BVG:2595-2609; loadSequential/loadOffline, BVG:1345-1464):
 // one wavefront parses the stream sequentially (all lanes in step, LDS-staged); offsets[n+1] out, err[0] != 0 on a bad stream

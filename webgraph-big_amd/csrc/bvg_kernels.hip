@@ -441,13 +441,14 @@ __global__ void plan_halo_kernel(const uint8_t* graph, uint64_t limit_byte, Offs
 // one wavefront per block: lanes stride over the block's nodes (coalesced offsets reads); the value kept is
 // the largest "own list + the W lists before it" — what the LDS pool must hold to decode that node at all
 __global__ void plan_maxd_kernel(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo,
-                                 uint32_t nblk, int coding, int window, uint32_t* maxd) {
+                                 uint32_t nblk, int coding, int window, uint32_t* maxd, uint64_t* bign, uint32_t* bigd) {
     const uint32_t k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= nblk) return;
     const unsigned lane = threadIdx.x & 63u;
     const uint32_t h = halo[k] == 0xFFFFFFFFu ? 0u : halo[k];
     const int64_t lo = (int64_t)first[k] - (int64_t)h, hi = (int64_t)first[k + 1];
     uint64_t m = 0, mrec = 0;
+    uint32_t bd = 0; uint64_t bn = first[k];                                  // the block's own longest list and its node (not the halo's)
     uint32_t prevd = 0;                                                       // d of node x-64 (previous chunk, same lane)
     for (int64_t x0 = lo; x0 < hi; x0 += 64) {
         const int64_t x = x0 + lane;
@@ -459,6 +460,7 @@ __global__ void plan_maxd_kernel(const uint8_t* graph, uint64_t limit_byte, Offs
             dd = d > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)d;
             const uint64_t rec = end - offsets[x];
             mrec = rec > mrec ? rec : mrec;
+            if (x >= (int64_t)first[k] && dd > bd) { bd = dd; bn = (uint64_t)x; }
         }
         uint64_t need = dd;
         for (int j = 1; j <= window && j < 64; j++) {
@@ -470,7 +472,12 @@ __global__ void plan_maxd_kernel(const uint8_t* graph, uint64_t limit_byte, Offs
         prevd = dd;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint64_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; const uint64_t t2 = __shfl_xor(mrec, o, 64); mrec = t2 > mrec ? t2 : mrec; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t t = __shfl_xor(m, o, 64); m = t > m ? t : m; const uint64_t t2 = __shfl_xor(mrec, o, 64); mrec = t2 > mrec ? t2 : mrec;
+        const uint32_t d2 = __shfl_xor(bd, o, 64); const uint64_t n2 = __shfl_xor(bn, o, 64);
+        if (d2 > bd || (d2 == bd && n2 < bn)) { bd = d2; bn = n2; }
+    }
+    if (lane == 0 && bign) { bign[k] = bn; bigd[k] = bd; }
     // bit 31 flags a record longer than the LDS stream window (4 KiB): such a block goes straight to the global tier.  (Tried: a
     // 16 KiB window in the largest LDS class for records up to 128 Kbit — 78 KiB workgroups beside tier 0 instead of one-wavefront
     // blocks with a 4 KiB footprint cost the 8 GiB eu scan 2.4 %, whether the plan filed the long records there or not.)
@@ -664,9 +671,9 @@ void launch_plan_longest(Offsets offsets, const uint64_t* first, uint32_t nblk, 
 }
 
 void launch_plan_maxd(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, const uint64_t* first, const uint32_t* halo, uint32_t nblk,
-                      int coding, int window, uint32_t* maxd, hipStream_t s) {
+                      int coding, int window, uint32_t* maxd, uint64_t* bign, uint32_t* bigd, hipStream_t s) {
     if (!nblk) return;
-    hipLaunchKernelGGL(plan_maxd_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, graph, limit_byte, offsets, first, halo, nblk, coding, window, maxd);
+    hipLaunchKernelGGL(plan_maxd_kernel, dim3((nblk + 3) / 4), dim3(256), 0, s, graph, limit_byte, offsets, first, halo, nblk, coding, window, maxd, bign, bigd);
 }
 
 void launch_mosaic_graph(const MosaicSrc& m, uint8_t* dst, uint64_t dst_bytes, int64_t cycles, hipStream_t s) {
