@@ -299,7 +299,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
     }
     // halo per boundary; boundaries whose reference chains reach further back than kMaxHalo nodes are removed.
     // Two rounds: the first one's per-block list sizes show which blocks owe their LDS class (or the giant kernel) to ONE large list; those
-    // are cut in front of that list and W + 1 nodes behind it, so that only the few nodes around it run at the class's low occupancy and
+    // are cut in front of that list and 2 W + 1 nodes behind it, so that only the few nodes around it run at the class's low occupancy and
     // the rest of the block goes back to tier 0 (the classes held 12 % of the blocks of the default workload and took 28 % of a scan).
     const bool refine = !knob("BVG_NO_LISTCUT") && sh->p.window_size <= kMaxWindow;
     for (int round = 0; round < 2; round++) {
@@ -333,7 +333,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
             if (e2 != hipSuccess) { (void)hipFree(d_first); (void)hipFree(d_halo); (void)hipFree(d_mask); return BVG_E_HIP; }
             if (want_cuts) {
                 // a block above the tier-0 capacity (about 2 000 elements of "worst list + window" / 2) with one list that is most of it
-                const uint64_t W1 = (uint64_t)sh->p.window_size + 1;
+                const uint64_t W1 = knob("BVG_LISTCUT_BEHIND") ? (uint64_t)atoi(knob("BVG_LISTCUT_BEHIND")) : 2 * (uint64_t)sh->p.window_size + 1;   // (behind the list: W + 1 would do for the nodes that copy from it, but chains through them reach back as well: 8 / 15 / 22 nodes measured 251 / 255 / 254 G edges/s)
                 std::vector<uint64_t> cut; cut.reserve(uniq.size() + 1024); size_t ncut = 0;
                 for (uint32_t k = 0; k < nblk; k++) {
                     cut.push_back(uniq[k]);
