@@ -338,7 +338,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
                 for (uint32_t k = 0; k < nblk; k++) {
                     cut.push_back(uniq[k]);
                     const uint64_t md = maxd[k] & 0x7FFFFFFFu;
-                    if (md / 2 + 64 > 1800 && bigd[k] >= (knob("BVG_LISTCUT_D") ? (uint32_t)atoi(knob("BVG_LISTCUT_D")) : 800u) && uniq[k + 1] - uniq[k] > 2 * W1 + 8) {
+                    if (md / 2 + 64 > 1800 && bigd[k] >= (knob("BVG_LISTCUT_D") ? (uint32_t)atoi(knob("BVG_LISTCUT_D")) : 500u) && uniq[k + 1] - uniq[k] > 2 * W1 + 8) {
                         if (bign[k] > uniq[k] + 4) { cut.push_back(bign[k]); ncut++; }
                         if (bign[k] + W1 + 4 < uniq[k + 1]) { cut.push_back(bign[k] + W1); ncut++; }
                     }
@@ -712,7 +712,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (rekey || pd.dirty) {
                 std::vector<uint32_t> L[12];                                     // tier 0, four LDS classes, giants (5), the generic kernel (6); 7..11: tier 0 and the classes of the lean scan kernel
                 uint64_t gneed = 0, gnodes = 0, glong = 0;
-                const double admit = knob("BVG_ADMIT") ? atof(knob("BVG_ADMIT")) : 0.5;   // share of a block's worst "list + window" that tier 0 of the scan kernel must hold
+                const double admit = knob("BVG_ADMIT") ? atof(knob("BVG_ADMIT")) : 0.3;   // share of a block's worst "list + window" that tier 0 of the scan kernel must hold
                 for (uint32_t i = 0; i < nblocks; i++) {
                     const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
                     const bool long_record = (pl.h_maxd[lo + i] >> 31) != 0;
