@@ -352,6 +352,13 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
                     continue;
                 }
             }
+            if (dbg_on()) {                                                // how many nodes the blocks decode a second time (their halos)
+                std::vector<uint64_t> hm(nblk);
+                if (hipMemcpy(hm.data(), d_mask, (size_t)nblk * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess) {
+                    uint64_t hn = 0; for (uint32_t k = 0; k < nblk; k++) hn += (uint64_t)__builtin_popcountll(halo[k] ? hm[k] & (halo[k] >= 64 ? ~0ull : ((1ull << halo[k]) - 1ull)) : 0ull);
+                    fprintf(stderr, "[bvg] plan: %u blocks, %llu halo nodes (%.1f %% of %lld nodes)\n", nblk, (unsigned long long)hn, 100.0 * (double)hn / (double)n, (long long)n);
+                }
+            }
             plan.d_first = d_first; plan.d_halo = d_halo; plan.d_mask = d_mask;
             plan.nblk = nblk; plan.h_first = uniq; plan.h_maxd.swap(maxd);
             plan.version = next_plan_version();
