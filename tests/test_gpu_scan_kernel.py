@@ -12,7 +12,7 @@ from bvrecords import Record, assemble
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL", "BVG_SCAN_WAVES", "BVG_GIANT", "BVG_WIDE_HALF")
+KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL", "BVG_SCAN_WAVES", "BVG_GIANT", "BVG_WIDE_HALF", "BVG_NO_LISTCUT")
 
 
 @pytest.fixture(autouse=True)
@@ -270,3 +270,32 @@ def test_reference_free_lists_with_intervals_decoded_in_place(W, oracle):
         ra, oa = g.scan(a, b), og.scan(a, b)
         assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (a, b)
     g.close()
+
+
+def test_plan_cuts_blocks_around_large_lists(W, tools, oracle, monkeypatch):
+    """The block plan puts a boundary in front of every list of 500 successors or more and 2 W + 1 nodes behind it, so that an LDS class
+    (few wavefronts per CU) decodes only the nodes that touch such a list: more, smaller blocks -- and the same successors
+    (BVGraph.java:995-1097 knows nothing of blocks: any cut must be invisible)."""
+    n = 15000
+    st = tools.synth_store(n, seed=61, synth=tools.eu_like(max_deg=30000, tail_alpha=1.6, mean_deg=40.0), threads=4)
+    og = _og(oracle, st)
+    o = og.scan()
+    blocks = {}
+    for cut in (True, False):
+        if cut: monkeypatch.delenv("BVG_NO_LISTCUT", raising=False)
+        else: monkeypatch.setenv("BVG_NO_LISTCUT", "1")
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+        for _ in range(3):
+            r = g.scan()
+            assert _same(r, o), cut
+        blocks[cut] = r["lean_blocks"] + r["slow_blocks"]
+        rng = np.random.default_rng(8)
+        for _ in range(6):
+            a, b = sorted(int(v) for v in rng.integers(0, n + 1, 2))
+            ra, oa = g.scan(a, b), og.scan(a, b)
+            assert (ra["arcs"], ra["chk"]) == (oa["arcs"], oa["chk"]), (cut, a, b)
+        deg, succ = g.decode_range(0, n)
+        odeg, osucc = og.decode_range(0, n)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), cut
+        g.close()
+    assert blocks[True] > blocks[False], blocks
