@@ -43,6 +43,7 @@ SHAPES = {
     "eu15mono": ("eu", dict(mean_deg=127.5), {}, 512, "eu-2015 stand-in at eu-2015 scale (round 2's form: one tile repeated): synthetic copy model, W=7 maxRef=3 minInterval=4 zeta3"),
     "eu": ("eu", {}, {}, 0, "eu-2015-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
     "web": ("web", {}, {}, 0, "cnr/uk-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
+    "uk": ("web", dict(mean_deg=44.0), {}, 0, "uk-2007-05-shaped synthetic at its density (35 arcs per node; copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
     "w0": ("web", {}, dict(window_size=0, max_ref_count=0, min_interval_length=0), 0, "uk-2007-05 re-store stand-in (window=0 maxRef=0, zeta3 residuals only)"),
 }
 # the 8 bases of the eu15 mosaic: (seed, eu_like overrides).  Mean outdegree ~86 over the cycle (eu-2015: 85.7); the tiles differ in
