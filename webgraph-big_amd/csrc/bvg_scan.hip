@@ -55,6 +55,10 @@ using namespace rows;
 #define BVG_SCAN_CHUNK 8
 #endif
 constexpr uint32_t kNoList = 0xFFFFu;
+#ifndef BVG_SCAN_MINTASK
+#define BVG_SCAN_MINTASK 1
+#endif
+constexpr uint32_t kScanMinTask = BVG_SCAN_MINTASK;   // shortest position task: 1 (a level of a sparse graph holds ~70 positions: one or two per lane and no loop to speak of; 4 cost the web shape 6 %)
 constexpr uint32_t kChunk = BVG_SCAN_CHUNK;    // leaf elements per lane and pass (a kept copy block of a web graph is ~9 elements long)
 
 typedef uint32_t T;
@@ -809,7 +813,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 // S in one step: sum_i ceil(d_i / S) <= W / S + N - N / S < 64 once S >= W / (64 - N)  (N lists, W positions in all)
                 const uint32_t Wl = wave_sum32(mem ? d : 0u), Nl = (uint32_t)__popcll(ballot(mem));
 #ifdef BVG_OLD_S
-                uint32_t S = (Wl + 63u) >> 6; if (S < kMinTask) S = kMinTask;
+                uint32_t S = (Wl + 63u) >> 6; if (S < kScanMinTask) S = kScanMinTask;
                 uint32_t Tn = 0;
                 for (int it = 0; it < 6; it++) {
                     Tn = 0;
@@ -821,7 +825,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 }
 #else
                 uint32_t S = Nl < 64u ? (Wl + (63u - Nl)) / (64u - Nl) : 0x7FFFFFFFu;
-                if (S < kMinTask) S = kMinTask;
+                if (S < kScanMinTask) S = kScanMinTask;
                 uint32_t Tn = 0;
                 if (mem) { Tn = (uint32_t)((float)d / (float)S); while (Tn * S < d) Tn++; while (Tn > 1u && (Tn - 1u) * S >= d) Tn--; }
 #endif
