@@ -13,6 +13,10 @@ streams concatenated on the device and the cycle repeated 128 times (bvg_mosaic;
 nodes, ~92 G arcs (eu-2015: 1.07 G nodes, 91.8 G arcs), a ~30 GB .graph stream resident in HBM, two orders of magnitude beyond the
 256 MiB Infinity Cache.  No LAW dataset can reach the GPU box (no network), hence "stand-in".  `--shape eu15mono` is round 2's form
 of it (ONE 2^21-node tile repeated 512 times), `eu` round 1's smaller graph (8 GiB, 26 G arcs), `web` / `w0` BASELINE configs 3 / 2.
+`--shape cnr` is the one REAL web graph in the tree: the reference's own fixture cnr-2000 (tests/golden/, byte-identical to
+slow/it/unimi/dsi/big/webgraph/cnr-2000.* of the reference; 325 557 nodes, 3.2 M arcs, W=7 maxRef=3 minInterval=3), its stream repeated
+on the device (bvg_mosaic of one base) to 8 GiB -- real LAW structure (24 % empty nodes, chains of depth 3, 9.9 arcs per node) at a size
+that defeats the caches.
 `--basename PATH` benchmarks a real BVGraph instead (PATH.properties / .graph / .offsets, as test/SpeedTest.java:117-146 takes it):
 loaded through bvg_open, sample node ranges gated against the CPU oracle, the CPU baseline timed on a prefix of its nodes.
 
@@ -45,7 +49,12 @@ SHAPES = {
     "web": ("web", {}, {}, 0, "cnr/uk-shaped synthetic (copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
     "uk": ("web", dict(mean_deg=44.0), {}, 0, "uk-2007-05-shaped synthetic at its density (35 arcs per node; copy model, W=7 maxRef=3 minInterval=4 zeta3)"),
     "w0": ("web", {}, dict(window_size=0, max_ref_count=0, min_interval_length=0), 0, "uk-2007-05 re-store stand-in (window=0 maxRef=0, zeta3 residuals only)"),
+    "cnr": ("golden", {}, {}, 0, "cnr-2000 (LAW; the reference's fixture, W=7 maxRef=3 minInterval=3 zeta3) tiled on the device"),
 }
+GOLDEN = os.path.join(ROOT, "tests", "golden", "cnr-2000")
+KERNEL_REV = "r04"      # profiles/traffic.json entries measured on other kernels are not quoted
+VALU_PEAK_WINSTR_PER_S = 1024 / 1.83e-9   # 256 CUs x 4 SIMDs, one wave-instruction per 1.83 ns each (profiles/r03_valu_rates.txt, measured on the card)
+VALU_FLOOR_PER_ARC = 30.0 / 64.0          # ~30 lane-operations of decode + checksum per arc on 64 lanes
 # the 8 bases of the eu15 mosaic: (seed, eu_like overrides).  Mean outdegree ~86 over the cycle (eu-2015: 85.7); the tiles differ in
 # density, in how much they copy and in how long their copy blocks, intervals and residual lists are.
 MIX = [(0, dict(mean_deg=127.5)),
@@ -75,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-gib", type=float, default=1.0, help="size of the stream the CPU baseline scans")
     ap.add_argument("--no-verify", action="store_true", help="skip the per-tile checksum gate against the CPU oracle")
+    ap.add_argument("--no-index-leg", action="store_true", help="skip the three index-less scans behind the timed region (value_no_index)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on a one-GPU box)")
     ap.add_argument("--echo-ranks", action="store_true", help="plumbing test: every rank prints 'rank r of w' and exits before touching the GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -117,7 +127,10 @@ def main():
 
     # ---- input: a real graph from disk, or synthetic bases generated + compressed on the host, uploaded, tiled on the device ----
     t0 = time.time()
-    threads = min(os.cpu_count() or 1, 64)
+    # host threads of THIS rank: the ranks of one node share its cores (8 ranks generating with every core each would oversubscribe the
+    # host 8x); with a launcher the synthetic bases are generated ONCE, by rank 0, and handed to the others through /dev/shm
+    ncpu = effective_cpus(os.cpu_count() or 1)
+    threads = max(1, min(ncpu // max(world, 1), 64))
     kind, skw, pkw, tiles_default, wl = SHAPES[args.shape]
     free0 = torch.cuda.mem_get_info(dev)[0]
     sts, bases, copies = [], [], 1
@@ -130,13 +143,31 @@ def main():
         n_graph = g.num_nodes()
         args.base_nodes = n_graph
     else:
-        if not args.base_nodes:
-            args.base_nodes = (1 << 20) if kind == "mix" else (1 << 21)
-        params = W.default_params(**pkw)
-        if kind == "mix":
-            sts = [T.synth_store(args.base_nodes, seed=sd, params=params, synth=T.eu_like(**kw), threads=threads) for sd, kw in MIX]
+        if kind == "golden":
+            sts = [golden_store(GOLDEN)]                                  # the reference's fixture, read from tests/golden/ (it travels with the repo)
+            args.base_nodes = int(sts[0].params.nodes)
         else:
-            sts = [T.synth_store(args.base_nodes, seed=0, params=params, synth=T.eu_like(**skw) if kind == "eu" else T.web_like(**skw), threads=threads)]
+            if not args.base_nodes:
+                args.base_nodes = (1 << 20) if kind == "mix" else (1 << 21)
+            params = W.default_params(**pkw)
+
+            def generate(nthreads):
+                if kind == "mix":
+                    return [T.synth_store(args.base_nodes, seed=sd, params=params, synth=T.eu_like(**kw), threads=nthreads) for sd, kw in MIX]
+                return [T.synth_store(args.base_nodes, seed=0, params=params, synth=T.eu_like(**skw) if kind == "eu" else T.web_like(**skw), threads=nthreads)]
+            if dist is not None and world > 1:
+                share = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bvg_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
+                if rank == 0:
+                    sts = generate(max(1, min(ncpu, 64)))                 # the other ranks wait at the barrier: rank 0 may use every core
+                    save_stores(share, sts)
+                dist.barrier()
+                if rank != 0:
+                    sts = load_stores(share)
+                dist.barrier()
+                if rank == 0:
+                    remove_stores(share)
+            else:
+                sts = generate(threads)
         gen_s = time.time() - t0
         cycle_bytes = sum(len(st.graph) for st in sts)
         cycle_nodes = args.base_nodes * len(sts)
@@ -212,9 +243,15 @@ def main():
                 rg = g.scan(a0, a0 + span)
                 assert (rg["arcs"], rg["chk"]) == (ro["arcs"], ro["chk"]), "GPU scan of nodes [%d, %d) disagrees with the CPU oracle" % (a0, a0 + span)
             del og
-    if scaling == "strong" and world > 1 and rank == 0:
-        whole = g.scan()                                                 # the one-piece scan of the replica: what the shards must add up to
-        assert (whole["arcs"], whole["chk"]) == (tot_arcs, tot_chk), "reduced shards disagree with the one-piece scan"
+    if scaling == "strong" and world > 1 and not args.no_verify:
+        # Every rank gates ITS OWN shard (no rank scans -- or indexes -- the whole replica): the tiles above against the CPU oracle, and
+        # the shard as a whole against the sum of its pieces scanned one by one through the same handle (additivity: the checksum is a
+        # plain sum over arcs, so the pieces of [lo, hi) must add up to the shard's own {arcs, chk}); the shards' sum is the all-reduce.
+        cuts = sorted({lo, hi} | {lo + (hi - lo) * i // 7 for i in range(1, 7)})
+        pa = pc = 0
+        for a0, a1 in zip(cuts[:-1], cuts[1:]):
+            rp = g.scan(a0, a1); pa += rp["arcs"]; pc = (pc + rp["chk"]) & 0xFFFFFFFFFFFFFFFF
+        assert (pa, pc) == (int(r["arcs"]), int(r["chk"])), "rank %d: the pieces of the shard do not add up to the shard" % rank
 
     if dist is not None:
         dist.barrier()
@@ -228,13 +265,33 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    my_k_ms = float(np.mean(kernel_ms))
     if dist is not None:
         elapsed = S.allreduce_max(elapsed, device=cuda)
-        k_ms = S.allreduce_max(float(np.mean(kernel_ms)), device=cuda)
+        k_ms = S.allreduce_max(my_k_ms, device=cuda)
         idx_all, lean_all = S.allreduce_scan(int(r["index_entries"]), int(r["lean_blocks"]), device=cuda)   # what every rank scanned with (untimed bookkeeping)
+        per_rank_ms = S.allgather_float(my_k_ms, rank, world, device=cuda)                                  # shard imbalance: the slowest rank sets the step
+        per_rank_idx = S.allgather_float(float(r["index_entries"]), rank, world, device=cuda)
     else:
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = my_k_ms
         idx_all, lean_all = int(r["index_entries"]), int(r["lean_blocks"])
+        per_rank_ms, per_rank_idx = [my_k_ms], [float(r["index_entries"])]
+
+    # ---- the index-less steady state (behind the timed region): the same scan through a flyweight that neither builds nor reads the
+    # residual skip index (bvg_tuning.no_index) -- what a consumer that scans a graph ONCE gets -- and how many scans the index takes to pay back
+    no_index = None
+    if not args.no_index_leg:
+        g0 = g.copy(); g0.set_tuning(block_bits=args.block_bits, no_index=True); g0.set_node_base(g.node_base())
+        rn = g0.scan(lo, hi)                                              # (tier learning of the index-less handle)
+        assert (rn["arcs"], rn["chk"]) == (int(r["arcs"]), int(r["chk"])), "the index-less scan disagrees with the indexed one"
+        torch.cuda.synchronize(); tn0 = time.perf_counter()
+        for _ in range(3):
+            rn = g0.scan(lo, hi)
+        torch.cuda.synchronize(); tn = (time.perf_counter() - tn0) / 3
+        no_index = {"s_per_step": tn, "index_entries": int(rn["index_entries"]), "lean_blocks": int(rn["lean_blocks"])}
+        del g0
+        if dist is not None:
+            no_index["s_per_step"] = S.allreduce_max(tn, device=cuda)
 
     if rank == 0:
         edges_per_s = tot_arcs * args.steps / elapsed
@@ -247,7 +304,7 @@ def main():
             "metric": "decoded edges/s, full sequential successor scan", "value": edges_per_s, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": steady_s * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32" if n_graph <= 0xFFFFFF00 else "u64",
-            "data": "synthetic",
+            "data": ("real: %s" % args.basename) if args.basename else ("real LAW graph cnr-2000 (the reference's fixture), its stream repeated on the device" if kind == "golden" else "synthetic"),
             "config": {"workload": wl + (" [stand-in: no LAW dataset on the box]" if args.shape.startswith("eu15") and not args.basename else ""), "shape": args.basename or args.shape,
                        "nodes": n_graph * (world if scaling == "weak" else 1), "arcs": tot_arcs, "graph_bytes": total_gbytes,
                        "nodes_per_gpu": hi - lo, "arcs_per_gpu": int(r["arcs"]), "graph_bytes_per_gpu": gbytes,
@@ -262,11 +319,30 @@ def main():
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
             "index": {"skip_entries_rank0": int(r["index_entries"]), "skip_entries_all_ranks": idx_all, "lean_blocks_rank0": int(r["lean_blocks"]), "lean_blocks_all_ranks": lean_all},
             "index_build_s": max(first_scan_s - steady_s, 0.0), "hbm_resident_bytes": int(resident),
+            "per_rank_kernel_ms": {"min": min(per_rank_ms), "mean": float(np.mean(per_rank_ms)), "max": max(per_rank_ms), "all": per_rank_ms},
+            "imbalance": max(per_rank_ms) / max(float(np.mean(per_rank_ms)), 1e-9),
+            "per_rank_index_entries": [int(v) for v in per_rank_idx],
             "host": {"generate_s": gen_s, "upload_s": upload_s, "tile_s": tile_s, "first_scan_s": first_scan_s},
         }
-        t = measured_traffic(args.basename or args.shape, copies, args.base_nodes, world, scaling)
+        if no_index is not None:
+            # steady rate WITHOUT the index, and the number of indexed scans after which building it has paid for itself
+            v0 = tot_arcs / no_index["s_per_step"]
+            out["value_no_index"] = v0
+            out["no_index"] = {"ms_per_step": no_index["s_per_step"] * 1e3, "steps": 3, "index_entries_used": no_index["index_entries"], "lean_blocks": no_index["lean_blocks"],
+                               "how": "bvg_copy() flyweight with bvg_tuning.no_index = 1: same stream, plan and offsets in HBM, no skip entries, no validation marks (every block on the checking kernels)"}
+            gain = no_index["s_per_step"] - steady_s
+            out["index_break_even_scans"] = (out["index_build_s"] / gain) if gain > 0 else None
+        t = measured_pmc(args.basename or args.shape, copies, args.base_nodes, world, scaling)
         if t:
-            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t["hbm_bytes_per_launch"], t.get("source")
+            if t.get("valu_per_arc"):
+                # the fraction that matters for THIS kernel: vector-instruction issue.  VALU wave-instructions per arc from the
+                # PMC pass on file for this very workload and kernel revision x the arcs/s measured NOW, against the issue peak measured on the card.
+                ach = t["valu_per_arc"] * edges_per_s / max(world, 1)
+                out["roofline_valu"] = {"bound": "valu-issue", "achieved": ach, "peak": VALU_PEAK_WINSTR_PER_S, "unit": "wave-instr/s", "frac": ach / VALU_PEAK_WINSTR_PER_S,
+                                        "valu_per_arc": t["valu_per_arc"], "salu_per_arc": t.get("salu_per_arc"), "lds_per_arc": t.get("lds_per_arc"), "active_lanes": t.get("active_lanes"),
+                                        "floor_valu_per_arc": VALU_FLOOR_PER_ARC, "x_floor": t["valu_per_arc"] / VALU_FLOOR_PER_ARC,
+                                        "edges_per_s_at_floor": VALU_PEAK_WINSTR_PER_S / VALU_FLOOR_PER_ARC, "source": t.get("valu_source")}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sts, bases, args.basename, effective_cpus(threads), args.cpu_gib)   # one thread per CPU the box really grants
         print(json.dumps(out))
@@ -290,17 +366,69 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def measured_traffic(shape, tiles, base_nodes, world, scaling):
-    """HBM bytes per launch from a PMC pass of THIS workload, if one is on file (profiles/traffic.json, written by
-    profiles/r02/collect_pmc.py with the configuration it was measured on); never a figure from another configuration."""
+def measured_pmc(shape, tiles, base_nodes, world, scaling):
+    """Counter figures per launch from a PMC pass of THIS workload on THIS kernel revision, if one is on file (profiles/traffic.json:
+    HBM bytes, VALU / SALU / LDS wave-instructions per arc, active lanes -- with the command they came from); never a figure from
+    another configuration or from an earlier round's kernels."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return None
     for e in rec.get("runs", []):
+        if e.get("rev") != KERNEL_REV:
+            continue
         if (e.get("shape"), e.get("tiles"), e.get("base_nodes"), e.get("n_gpus", 1), e.get("scaling", "weak")) == (shape, tiles, base_nodes, world, scaling if world > 1 else e.get("scaling", "weak")):
-            return e["hbm_bytes_per_launch"], e.get("source")
+            return e
     return None
+
+
+class _Store:
+    """What bench.py needs of a stored graph (tooling.Stored's fields)."""
+
+    def __init__(self, params, graph, offsets, stats):
+        self.params, self.graph, self.offsets, self.stats = params, graph, offsets, stats
+
+
+def golden_store(basename):
+    """The reference's fixture as a stored graph: properties parsed by the library's own parser, the .graph bytes verbatim, the
+    offsets decoded from the .offsets file (bvg_decode_offsets, host side)."""
+    import numpy as np
+    import webgraph_big_amd as W
+    p = W.parse_properties(open(basename + ".properties").read())
+    graph = np.fromfile(basename + ".graph", dtype=np.uint8)
+    offs = W.decode_offsets(np.fromfile(basename + ".offsets", dtype=np.uint8), int(p.nodes), int(p.offset_coding))
+    return _Store(p, graph, offs, {"arcs": int(p.arcs)})
+
+
+def save_stores(prefix, sts):
+    import numpy as np
+    for i, st in enumerate(sts):
+        np.save("%s_%d_g.npy" % (prefix, i), st.graph); np.save("%s_%d_o.npy" % (prefix, i), st.offsets)
+        with open("%s_%d_p.bin" % (prefix, i), "wb") as f:
+            f.write(bytes(st.params))
+        with open("%s_%d_s.json" % (prefix, i), "w") as f:
+            json.dump({k: int(v) for k, v in st.stats.items()}, f)
+    with open(prefix + "_n", "w") as f:
+        f.write(str(len(sts)))
+
+
+def load_stores(prefix):
+    import numpy as np
+    import webgraph_big_amd as W
+    out = []
+    for i in range(int(open(prefix + "_n").read())):
+        p = W.Params.from_buffer_copy(open("%s_%d_p.bin" % (prefix, i), "rb").read())
+        out.append(_Store(p, np.load("%s_%d_g.npy" % (prefix, i)), np.load("%s_%d_o.npy" % (prefix, i)), json.load(open("%s_%d_s.json" % (prefix, i)))))
+    return out
+
+
+def remove_stores(prefix):
+    import glob
+    for f in glob.glob(prefix + "_*"):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
 
 
 def effective_cpus(threads):

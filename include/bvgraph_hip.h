@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BVG_ABI_VERSION 2
+#define BVG_ABI_VERSION 3
 
 /* Status codes; each maps 1:1 to the exception class the reference throws at the cited line. */
 typedef enum bvg_status {
@@ -125,9 +125,10 @@ int bvg_outdegrees(bvg_graph* g, int64_t from, int64_t to, int32_t* out);
  * to == from+1 is successors(x) (BVG:860-867).  If succ_cap is too small returns BVG_E_CAPACITY
  * with *n_succ = required size (succ may be NULL to query).  outdeg may be NULL. */
 int bvg_decode_range(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
-/* Same with the successors as 32-bit ids: graphs of at most 2^32 nodes (ids + node base below 2^32; otherwise BVG_E_UNSUPPORTED), host
- * buffers only.  Half the bytes over PCIe, which bounds this path; the caller widens (NodeIterator.successorBigArray() hands out
- * longs, NodeIterator.java:80-96).  A missing successor of a malformed stream (-1 above) reads 0xFFFFFFFF. */
+/* Same with the successors as 32-bit ids: graphs whose ids + node base stay BELOW 2^32 - 1 (nodes + node_base <= 0xFFFFFFFF; otherwise
+ * BVG_E_UNSUPPORTED), host buffers only.  Half the bytes over PCIe, which bounds this path; the caller widens
+ * (NodeIterator.successorBigArray() hands out longs, NodeIterator.java:80-96).  A missing successor of a malformed stream (-1 above) reads
+ * 0xFFFFFFFF -- never a legal id here, which is why the limit is one below 2^32 -- and the widening caller maps it back to -1. */
 int bvg_decode_range32(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, uint32_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Same, successor / outdegree buffers in device memory (stay in HBM for a downstream kernel). */
 int bvg_decode_range_dev(bvg_graph* g, int64_t from, int64_t to, void* d_outdeg, void* d_succ, uint64_t succ_cap, uint64_t* n_succ);
@@ -264,6 +265,9 @@ typedef struct bvg_tuning {
                                 such a graph still run the scan kernel, on 32-bit lists of ids relative to a per-block base */
     uint32_t force_slow;     /* 1 = route every block through the global-memory slow path (tests) */
     uint32_t reserved;       /* low byte 2 = experimental streaming kernel as tier 0; bits 8.. = its grab threshold */
+    uint32_t no_index;       /* 1 = calls on THIS handle neither build nor read the residual skip index (nor the validation marks, so every
+                                block stays on the checking kernels): what a cold consumer gets from a graph it scans once; bench.py times
+                                a bvg_copy() flyweight with it (`value_no_index`) beside the indexed steady state (ABI version 3) */
 } bvg_tuning;
 int bvg_set_tuning(bvg_graph* g, const bvg_tuning* t);
 

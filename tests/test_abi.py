@@ -23,11 +23,11 @@ def test_library_exports_every_declared_symbol(W):
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
-    assert lib.bvg_abi_version() == 2
+    assert lib.bvg_abi_version() == 3
 
 
 def test_struct_layouts_match_header(W):
-    assert C.sizeof(W.Params) == 56 and C.sizeof(W.ScanResult) == 72 and C.sizeof(W.Tuning) == 16
+    assert C.sizeof(W.Params) == 56 and C.sizeof(W.ScanResult) == 72 and C.sizeof(W.Tuning) == 20
 
 
 def test_host_side_entry_points(W, oracle):

@@ -256,6 +256,64 @@ def test_device_index_is_saved_and_loaded_back(W, tools, oracle, tmp_path, capfd
     h.close()
 
 
+def test_a_damaged_or_foreign_index_file_is_refused(W, tools, oracle, tmp_path):
+    """The lean scan kernel trusts the validation marks of basename.bvgidx, so the file is tied to EVERY byte of the stream and guarded
+    by a checksum of its own payload (format 2): a .graph rewritten in place with the same size and other bytes in the middle, a
+    flipped bit anywhere in the index, a mark turned from 'unvalidated' into 'validated', a halo beyond the kernels' limit, a truncated
+    file -- each is refused (IOException) and the graph still scans right, on an index it builds itself."""
+    import os
+    st = tools.synth_store(40000, seed=18, synth=tools.eu_like(mean_deg=60.0), threads=4)
+    base = str(tmp_path / "g"); st.write(base)
+    o = oracle.Graph.load(base).scan()
+    g = W.BVGraph.load(base)
+    g.scan(); r = g.scan()
+    assert r["chk"] == o["chk"] and r["lean_blocks"] > 0
+    idx = g.save_index(); g.close()
+    good = open(idx, "rb").read()
+
+    def refused(data):
+        open(idx, "wb").write(data)
+        os.utime(idx, None)
+        q = W.BVGraph.load(base)                                        # bvg_open tries the file by itself: a refusal must be silent and harmless
+        try:
+            with pytest.raises(W.IOException):
+                q.load_index(idx)
+            rr = q.scan(); rr = q.scan()
+            assert (rr["arcs"], rr["chk"]) == (o["arcs"], o["chk"])
+        finally:
+            q.close()
+
+    hdr = 128                                                           # sizeof(IndexHeader)
+    assert len(good) > hdr + 4096
+    for pos in (hdr + 3, len(good) // 2, len(good) - 5):                # a flipped bit in the plan, in the skip entries, in the values
+        bad = bytearray(good); bad[pos] ^= 0x10
+        refused(bytes(bad))
+    refused(good[:-8])                                                  # truncated
+    refused(good + b"\0" * 8)                                          # trailing bytes
+    bad = bytearray(good); bad[8] ^= 1                                  # format version
+    refused(bytes(bad))
+    # the same index against a stream whose MIDDLE bytes changed (same size, same first and last 64 KiB): not this index's graph
+    open(idx, "wb").write(good)
+    gbytes = bytearray(open(base + ".graph", "rb").read())
+    assert len(gbytes) > 3 * 65536
+    mid = len(gbytes) // 2
+    gbytes[mid] ^= 0x01
+    base2 = str(tmp_path / "g2")
+    for ext in (".properties", ".offsets"):
+        open(base2 + ext, "wb").write(open(base + ext, "rb").read())
+    open(base2 + ".graph", "wb").write(bytes(gbytes))
+    q = W.BVGraph.load(base2)
+    with pytest.raises(W.IOException):
+        q.load_index(idx)
+    q.close()
+    # and the untouched file still loads
+    q = W.BVGraph.load(base)
+    q.load_index(idx)
+    rr = q.scan()
+    assert (rr["arcs"], rr["chk"], rr["lean_blocks"]) == (o["arcs"], o["chk"], r["lean_blocks"])
+    q.close()
+
+
 def test_successors_as_32_bit_ids_for_the_host_path(W, small, oracle):
     """bvg_decode_range32: the same lists as bvg_decode_range, ids as uint32 (what the NodeIterator mirror moves over PCIe and widens,
     NodeIterator.java:80-96); refused when an id could pass 2^32."""

@@ -165,3 +165,45 @@ def test_cnr2000_symmetrize(cnr_gpu, cnr_csr):
     keys = np.unique(np.concatenate([src * n + gsucc, gsucc * n + src]))
     assert np.array_equal(soff, np.concatenate([[0], np.cumsum(np.bincount(keys // n, minlength=n))]).astype(np.uint64))
     assert np.array_equal(ssucc, keys % n)
+
+
+def test_cnr2000_tiled_on_the_device_matches_the_golden_across_the_seams(W, oracle, cnr_golden, cnr_csr):
+    """bench.py --shape cnr: the reference's fixture repeated on the device (bvg_mosaic of ONE base; BV records are translation
+    invariant).  Tile j must be the golden (BVGraphTest.testLarge's expected lists) shifted by j * n -- also for the nodes on either
+    side of every seam, whose block, halo and stream window straddle two copies of the stream -- and the scan's checksum must be the
+    oracle's, tile by tile and across seams."""
+    import os
+    from conftest import CNR
+    base = W.BVGraph.load(CNR)
+    n = base.num_nodes()
+    copies = 5
+    g = W.mosaic([base], copies)
+    assert g.num_nodes() == copies * n and g.num_arcs() == copies * base.num_arcs()
+    deg, succ = cnr_csr
+    cum = np.concatenate([[0], np.cumsum(deg, dtype=np.int64)])
+    og = oracle.Graph.load(CNR)
+    for _ in range(2):                                                  # (the second scan runs indexed)
+        r = g.scan()
+        assert r["arcs"] == copies * int(cum[-1]) and r["nodes"] == copies * n
+    whole = 0
+    for j in range(copies):
+        o = og.scan(0, n, node_base=j * n)
+        t = g.scan(j * n, (j + 1) * n)
+        assert (t["arcs"], t["chk"]) == (o["arcs"], o["chk"]), "tile %d" % j
+        whole = (whole + o["chk"]) & 0xFFFFFFFFFFFFFFFF
+    assert r["chk"] == whole
+    K = 3000
+    for j in range(1, copies):                                          # K nodes on either side of seam j
+        d, s = g.decode_range(j * n - K, j * n + K)
+        assert np.array_equal(d, np.concatenate([deg[n - K:], deg[:K]]))
+        want = np.concatenate([succ[cum[n - K]:] + (j - 1) * n, succ[:cum[K]] + j * n])
+        assert np.array_equal(s, want), "seam %d" % j
+        oa = og.scan(n - K, n, node_base=(j - 1) * n); ob = og.scan(0, K, node_base=j * n)
+        sc = g.scan(j * n - K, j * n + K)
+        assert sc["arcs"] == oa["arcs"] + ob["arcs"] and sc["chk"] == (oa["chk"] + ob["chk"]) & 0xFFFFFFFFFFFFFFFF
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.integers(0, copies * n, 2000), np.array([j * n + k for j in range(1, copies) for k in (-1, 0, 1, 7)])]).astype(np.int64)
+    bd, bs = g.successors_batch(xs)
+    exp = [succ[cum[x % n]:cum[x % n + 1]] + (x // n) * n for x in xs.tolist()]
+    assert np.array_equal(bs, np.concatenate(exp)) and np.array_equal(bd, np.array([len(e) for e in exp], dtype=np.int32))
+    g.close(); base.close()

@@ -1,8 +1,9 @@
 """webgraph-big_amd — MI355X-native BVGraph successor-list decoding.
 
-The package holds only what the decode path needs: csrc/ (HIP kernels + C ABI), bvgraph.py (host-side
-mirror of the reference's ImmutableGraph / NodeIterator / LazyLongIterator API over the C ABI) and
-tools.py (CPU encoder + synthetic graphs, for tests and bench input generation only).
+The package holds only what the decode path needs: csrc/ (HIP kernels + C ABI), host/ (the C++ mirror), bvgraph.py (host-side
+mirror of the reference's ImmutableGraph / NodeIterator / LazyLongIterator API over the C ABI) and shard.py (the node-range
+shard helpers bench.py and the tests share); experimental/ holds kernels that lost to the product's and are built only by
+`make experimental`.  The CPU encoder and the synthetic graph generators are test tooling and live outside the package (tooling/).
 """
 from ._abi import *  # noqa: F401,F403
 from ._abi import Params, ScanResult, Tuning, default_params  # noqa: F401

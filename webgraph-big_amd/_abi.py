@@ -32,7 +32,7 @@ class ScanResult(C.Structure):
 
 class Tuning(C.Structure):
     """bvg_tuning."""
-    _fields_ = [("block_bits", C.c_uint32), ("force_wide", C.c_uint32), ("force_slow", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("block_bits", C.c_uint32), ("force_wide", C.c_uint32), ("force_slow", C.c_uint32), ("reserved", C.c_uint32), ("no_index", C.c_uint32)]
 
 
 DELTA, GAMMA, GOLOMB, SKEWED_GOLOMB, UNARY, ZETA, NIBBLE = 1, 2, 3, 4, 5, 6, 7

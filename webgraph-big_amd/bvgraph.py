@@ -147,7 +147,7 @@ def lib():
         L.bvg_build_index.argtypes = [vp, i64, i64, C.POINTER(u64), C.POINTER(u64)]
         L.bvg_save_index.argtypes = [vp, C.c_char_p]
         L.bvg_load_index.argtypes = [vp, C.c_char_p]
-        if L.bvg_abi_version() != 2:
+        if L.bvg_abi_version() != 3:
             raise ImportError("libbvgraph_hip.so ABI mismatch")
         _LIB = L
     return _LIB
@@ -291,7 +291,7 @@ class _BatchSlot:
         self.deg = _pinned(batch_nodes, np.int32)
         # graphs whose ids fit 32 bits cross PCIe as uint32 (bvg_decode_range32): the transfer bounds this path, so half the bytes is
         # twice the rate; successor_array() widens to the longs of NodeIterator.successorBigArray()
-        self.dt = np.uint32 if graph.num_nodes() + graph.node_base() <= (1 << 32) else np.int64
+        self.dt = np.uint32 if graph.num_nodes() + graph.node_base() <= 0xFFFFFFFF else np.int64   # (0xFFFFFFFF is never an id on this transport: it stands for -1)
         self.succ = _pinned(max(1024, 32 * batch_nodes), self.dt)
         self.lo = self.hi = 0
         self.n_succ = 0
@@ -406,14 +406,18 @@ class NodeIterator:
         self._require_started()
         i = self._curr - self._b0
         v = self._succ[self._cum[i]:self._cum[i + 1]]
-        return v if v.dtype == np.int64 else v.astype(np.int64)        # (ids that crossed PCIe as uint32 are widened here)
+        if v.dtype == np.int64:
+            return v
+        w = v.astype(np.int64)                                         # (ids that crossed PCIe as uint32 are widened here)
+        w[v == 0xFFFFFFFF] = -1                                        # the stand-in for a missing successor of a malformed stream: -1, as on the int64 transport
+        return w
 
     successorBigArray = successor_array
 
     def batch(self):
         """The whole current batch at once: (first node, outdeg int32[], cum int64[], succ) — views valid until the next next_long()
         that leaves the batch (what a bulk consumer walks instead of one node at a time).  succ is uint32 for graphs whose ids fit
-        32 bits (as it crossed PCIe), int64 otherwise."""
+        32 bits (as it crossed PCIe: 0xFFFFFFFF there stands for the -1 of a malformed stream, never for a node), int64 otherwise."""
         self._require_started()
         return self._b0, self._deg, self._cum, self._succ
 
@@ -571,9 +575,10 @@ class BVGraph:
     def node_base(self):
         return getattr(self, "_node_base", 0)
 
-    def set_tuning(self, block_bits=0, force_wide=False, force_slow=False, stream=False, grab_threshold=0, legacy=False):
-        """stream=True selects the experimental streaming data-flow kernel (bvg_stream.hip) as tier 0."""
-        t = Tuning(block_bits, int(force_wide), int(force_slow), (2 if stream else (1 if legacy else 0)) | (int(grab_threshold) << 8))
+    def set_tuning(self, block_bits=0, force_wide=False, force_slow=False, stream=False, grab_threshold=0, legacy=False, no_index=False):
+        """stream=True selects the experimental streaming data-flow kernel (experimental/bvg_stream.hip) as tier 0; no_index=True makes
+        this handle scan without the residual skip index (neither built nor read)."""
+        t = Tuning(block_bits, int(force_wide), int(force_slow), (2 if stream else (1 if legacy else 0)) | (int(grab_threshold) << 8), int(no_index))
         _check(lib().bvg_set_tuning(self._h, C.byref(t)), "set_tuning")
 
     def offsets(self):

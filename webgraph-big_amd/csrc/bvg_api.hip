@@ -59,6 +59,9 @@ struct SkipIndex {
     uint32_t blk_lo = 0, blk_hi = 0;
     uint64_t total = 0; uint64_t* d_first = nullptr; uint16_t* d_bit = nullptr; void* d_val = nullptr; uint8_t* d_fmt = nullptr;
     bool wide = false;                        // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
+    bool failed = false;                      // the build of [blk_lo, blk_hi) failed (out of memory, malformed stream): no arrays; scans of those blocks run index-less and
+                                              // do NOT try again on their own (only bvg_build_index does)
+    uint64_t gen = 0;                         // identity of this snapshot: what a handle learned about blocks (tier lists, lean / row split) holds for ONE snapshot only
     std::vector<uint64_t> h_first;            // nblk + 1 entry indices (host copy: index_bytes of a range)
     std::vector<uint8_t> h_fmt;               // host copy of d_fmt: 1 = validated by the row kernel (the lean scan kernel may take the block)
     SkipIndex() = default; SkipIndex(const SkipIndex&) = delete; SkipIndex& operator=(const SkipIndex&) = delete;
@@ -139,8 +142,8 @@ struct bvg_graph {
     int skip_mode = 0; uint32_t* skip_cnt = nullptr;   // transient: set while this handle builds the skip index
     std::shared_ptr<SkipIndex> skip_building;          // transient: the index the fill pass (skip_mode 2) writes
     struct Pred {
-        uint64_t plan_version = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
-        std::vector<uint8_t> learned; std::vector<uint8_t> leanfail; uint64_t learned_version = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
+        uint64_t plan_version = 0, skip_gen = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
+        std::vector<uint8_t> learned; std::vector<uint8_t> leanfail; uint64_t learned_version = 0, learned_gen = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
     } pred;
 };
 
@@ -391,23 +394,35 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
 // The fill pass is also the VALIDATING pass: a block it decodes from end to end with the position logic (which refuses streams
 // that overlap, counts that contradict each other, ...) is marked fmt = 1, and only such blocks are given to the lean scan kernel.
 // The result replaces the plan's snapshot; scans that hold the old one keep it alive until they return.
-int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uint32_t bhi) {
+int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uint32_t bhi, bool retry_failed = false) {
     Shared* sh = g->sh;
     std::lock_guard<std::mutex> lk(sh->skip_mu);
     Plan& pl = *plp;
     {
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&pl.skip);
-        if (cur && cur->blk_lo <= blo && bhi <= cur->blk_hi) return 0;            // another thread built it meanwhile
-        if (cur) { blo = 0; bhi = pl.nblk; }                                      // a second range: index the whole graph once and for all
+        if (cur && !(cur->failed && retry_failed) && cur->blk_lo <= blo && bhi <= cur->blk_hi) return 0;   // another thread built it meanwhile (or failed to: not tried again here)
+        if (cur && !cur->failed) { blo = 0; bhi = pl.nblk; }                      // a second range: index the whole graph once and for all
     }
     const uint32_t nblk = pl.nblk;
     if (!nblk || sh->p.nodes == 0 || blo >= bhi) return 0;
     const int64_t nfrom = (int64_t)pl.h_first[blo], nto = (int64_t)pl.h_first[bhi];
     const bool build_wide = sh->wide || g->tun.force_wide;
     std::shared_ptr<SkipIndex> ix = std::make_shared<SkipIndex>();
-    ix->device = sh->device; ix->blk_lo = blo; ix->blk_hi = bhi; ix->wide = build_wide;
+    ix->device = sh->device; ix->blk_lo = blo; ix->blk_hi = bhi; ix->wide = build_wide; ix->gen = next_plan_version();
     auto publish = [&]() { std::atomic_store(&pl.skip, ix); return 0; };
-    auto give_up = [&]() { (void)hipGetLastError(); return 0; };                  // no index: the scans run without one
+    // no index: the scans run without one.  The failure is PUBLISHED (an empty snapshot of the same block range, unless a good index of
+    // other blocks exists already), so that later scans of these blocks do not pay the counting pass again and again; bvg_build_index() retries.
+    auto give_up = [&]() {
+        (void)hipGetLastError();
+        std::shared_ptr<SkipIndex> cur = std::atomic_load(&pl.skip);
+        if (!cur || cur->failed) {
+            std::shared_ptr<SkipIndex> fx = std::make_shared<SkipIndex>();
+            fx->device = sh->device; fx->blk_lo = blo; fx->blk_hi = bhi; fx->wide = build_wide; fx->failed = true; fx->gen = next_plan_version();
+            std::atomic_store(&pl.skip, fx);
+        }
+        if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: build of blocks [%u, %u) failed; scanning without it\n", blo, bhi);
+        return 0;
+    };
     DevBuf cnt_d;
     if (cnt_d.alloc((size_t)nblk * sizeof(uint32_t)) || hipMemset(cnt_d.p, 0, (size_t)nblk * sizeof(uint32_t)) != hipSuccess) return give_up();
     g->skip_mode = 1; g->skip_cnt = (uint32_t*)cnt_d.p;
@@ -461,7 +476,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     // The residual skip index is built the first time it would pay: a SCAN of >= 4096 nodes indexes the blocks it covers (a shard
     // of a multi-GPU scan builds its own part only; a later scan outside them indexes the whole graph), a materialising call
     // the whole graph once it covers a quarter of it.  bvg_build_index() does the same explicitly.
-    if (!batch && rows_default && g->skip_mode == 0 && !knob("BVG_NOSKIP") && (to - from) >= 4096 && nblocks) {
+    if (!batch && rows_default && g->skip_mode == 0 && !knob("BVG_NOSKIP") && !g->tun.no_index && (to - from) >= 4096 && nblocks) {
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&plp->skip);
         const bool covered = cur && cur->blk_lo <= lo && lo + nblocks <= cur->blk_hi;
         if (!covered && (!materialise || (to - from) >= sh->p.nodes / 4)) {
@@ -469,7 +484,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (r) return r;
         }
     }
-    const std::shared_ptr<SkipIndex> skx = g->skip_mode == 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));   // held for the whole call
+    std::shared_ptr<SkipIndex> skx0 = g->skip_mode == 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));
+    if (skx0 && g->skip_mode == 0 && (skx0->failed || g->tun.no_index)) skx0.reset();                // a failed build left no arrays; bvg_tuning.no_index: this handle scans without it
+    const std::shared_ptr<SkipIndex> skx = skx0;                                                       // held for the whole call
 
     if (nblocks > g->fail_cap) {                            // every block may fail over to the slow path
         (void)hipFree(g->d_fail); g->d_fail = nullptr;
@@ -709,11 +726,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const uint32_t pool0 = a.lds_pool_elems;
             const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u) | (fast_ok ? 32u : 0u) | (fast_ok ? (af.lds_pool_elems << 8) : 0u);
             const uint64_t cap0 = flow ? 6144 : pool0;                          // the flow kernel keeps long lists in its scratch area
-            const bool rekey = pd.plan_version != pl.version || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
+            const uint64_t sgen = (a.skip_first && skx) ? skx->gen : 0;         // the snapshot the marks / entry layouts come from: another one, another split
+            const bool rekey = pd.plan_version != pl.version || pd.skip_gen != sgen || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
             // what the cascade taught about a block is kept per block of the PLAN, so a scan of another node range (a shard, an
             // iterator batch, the bench's verification of single tiles) does not throw it away
-            if (pd.learned.size() != pl.nblk || pd.learned_version != pl.version || pd.learned_pool0 != pool0 || pd.learned_mode != pmode) {
-                pd.learned.assign(pl.nblk, 0); pd.leanfail.assign(pl.nblk, 0); pd.learned_version = pl.version; pd.learned_pool0 = pool0; pd.learned_mode = pmode;
+            if (pd.learned.size() != pl.nblk || pd.learned_version != pl.version || pd.learned_gen != sgen || pd.learned_pool0 != pool0 || pd.learned_mode != pmode) {
+                pd.learned.assign(pl.nblk, 0); pd.leanfail.assign(pl.nblk, 0); pd.learned_version = pl.version; pd.learned_gen = sgen; pd.learned_pool0 = pool0; pd.learned_mode = pmode;
             }
             if (rekey) pd.dirty = false;
             if (rekey || pd.dirty) {
@@ -746,7 +764,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     if (!L[c].empty()) HIPCHK(hipMemcpy(pd.d_lists + off, L[c].data(), L[c].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
                     off += L[c].size();
                 }
-                pd.plan_version = pl.version; pd.lo = lo; pd.n = nblocks; pd.pool0 = pool0; pd.giant_need = gneed;
+                pd.plan_version = pl.version; pd.skip_gen = sgen; pd.lo = lo; pd.n = nblocks; pd.pool0 = pool0; pd.giant_need = gneed;
             }
             // giants: global-memory pools sized to the largest list, allocated before anything is launched
             uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0;
@@ -1104,25 +1122,44 @@ template <typename F> static int guarded(F&& f) {
 // ---- the device index on disk (basename.bvgidx) ----
 // What a first scan builds -- the block plan (boundaries, halos, largest lists) and the residual skip index with its validation marks
 // -- written next to the graph so that the next process loads it instead of scanning the graph twice (the reference caches its own
-// index the same way: the .obl file of the offsets big list, checked against the file it was built from, BVG:1545-1555).  The file is
-// tied to the graph by size, parameters and a fingerprint of the stream's first and last 64 KiB.
+// index the same way: the .obl file of the offsets big list, checked against the file it was built from, BVG:1545-1555).
+// The lean scan kernel trusts the marks (it skips the checks a validated block cannot fail), so the file is tied to the graph by MORE
+// than size and date (format version 2): a hash of EVERY byte of the stream (one pass on the device), every parameter that shapes a
+// record (window, minimum interval length, zeta k, the five codings), and a checksum over the whole payload; every array is range-checked
+// on the way in (halo lengths, marks, monotone entry counts, sizes).  A file that fails any of it is refused (BVG_E_IO) and the index is
+// built from the stream as usual.
 struct IndexHeader {
-    char magic[8]; uint32_t version, block_bits; uint64_t graph_bytes, total_bits; int64_t nodes; uint64_t fingerprint;
+    char magic[8]; uint32_t version, block_bits; uint64_t graph_bytes, total_bits; int64_t nodes; uint64_t stream_hash;
     uint32_t window, wide, nblk, has_skip, skip_lo, skip_hi; uint64_t skip_total;
+    int32_t min_interval, zeta_k, cod_outdegree, cod_block, cod_residual, cod_reference, cod_block_count; uint32_t skip_min, skip_every, pad0;
+    uint64_t payload_hash;                      // of everything behind the header, array by array (host arrays on the host, device arrays on the device)
 };
-static const char kIndexMagic[8] = {'B', 'V', 'G', 'I', 'D', 'X', '1', 0};
+static const char kIndexMagic[8] = {'B', 'V', 'G', 'I', 'D', 'X', '2', 0};
 
-static int graph_fingerprint(const Shared* sh, uint64_t* out) {
-    const uint64_t piece = 65536, n = sh->nbytes;
-    std::vector<uint8_t> buf;
-    const uint64_t a = std::min<uint64_t>(piece, n), b = n > piece ? std::min<uint64_t>(piece, n - a) : 0;
-    buf.resize((size_t)(a + b));
-    if (a) HIPCHK(hipMemcpy(buf.data(), sh->d_graph, (size_t)a, hipMemcpyDeviceToHost));
-    if (b) HIPCHK(hipMemcpy(buf.data() + a, sh->d_graph + (n - b), (size_t)b, hipMemcpyDeviceToHost));
-    uint64_t h = 1469598103934665603ull ^ n;                              // FNV-1a
-    for (uint8_t c : buf) { h ^= c; h *= 1099511628211ull; }
-    *out = h;
+// position-keyed word hash of a device array (launch_hash_words), synchronous
+static int device_hash(bvg_graph* g, const void* d, uint64_t bytes, uint64_t* out) {
+    DevBuf acc;
+    if (acc.alloc(8)) return BVG_E_NOMEM;
+    HIPCHK(hipMemsetAsync(acc.p, 0, 8, g->stream));
+    if (bytes) launch_hash_words(d, bytes, (unsigned long long*)acc.p, g->stream);
+    HIPCHK(hipMemcpyAsync(out, acc.p, 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
     return 0;
+}
+// the same function on the host (the small per-block arrays never leave it)
+static uint64_t host_hash(const void* p, uint64_t nbytes) {
+    const uint8_t* b = (const uint8_t*)p; const uint64_t nw = nbytes >> 3; uint64_t h = 0;
+    for (uint64_t i = 0; i < nw; i++) { uint64_t w; memcpy(&w, b + 8 * i, 8); uint64_t z = w + (i + 1) * 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27; h += z; }
+    if (nbytes & 7) { uint64_t t = 0; for (uint64_t k = nw << 3; k < nbytes; k++) t = (t << 8) | b[k]; uint64_t z = t + (nw + 1) * 0x9E3779B97F4A7C15ull + (nbytes & 7); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27; h += z; }
+    return h;
+}
+static inline uint64_t fold_hash(uint64_t acc, uint64_t part, uint64_t slot) { return (acc ^ (part + slot * 0xD6E8FEB86659FD93ull)) * 0xFF51AFD7ED558CCDull; }   // the arrays in order
+
+static void fill_header_params(const Shared* sh, IndexHeader& h) {
+    h.graph_bytes = sh->nbytes; h.total_bits = sh->total_bits; h.nodes = sh->p.nodes; h.window = (uint32_t)sh->p.window_size;
+    h.min_interval = sh->p.min_interval_length; h.zeta_k = sh->p.zeta_k; h.cod_outdegree = sh->p.outdegree_coding; h.cod_block = sh->p.block_coding;
+    h.cod_residual = sh->p.residual_coding; h.cod_reference = sh->p.reference_coding; h.cod_block_count = sh->p.block_count_coding;
+    h.skip_min = kSkipMin; h.skip_every = kSkipEvery;
 }
 static bool put_dev(FILE* f, const void* d, size_t bytes) {               // device array -> file, in pieces
     std::vector<uint8_t> buf(std::min<size_t>(bytes ? bytes : 1, (size_t)64 << 20));
@@ -1149,17 +1186,31 @@ static int save_index_impl(bvg_graph* g, const char* path) {
     int r = build_plan(g, block_bits_of(g), plp); if (r) return r;
     const Plan& pl = *plp;
     std::shared_ptr<SkipIndex> ix = std::atomic_load(&plp->skip);
+    if (ix && ix->failed) ix.reset();                                      // (a failed build left nothing to save)
     IndexHeader h{};
-    memcpy(h.magic, kIndexMagic, 8); h.version = 1; h.block_bits = pl.block_bits; h.graph_bytes = sh->nbytes; h.total_bits = sh->total_bits; h.nodes = sh->p.nodes;
-    r = graph_fingerprint(sh, &h.fingerprint); if (r) return r;
-    h.window = (uint32_t)sh->p.window_size; h.nblk = pl.nblk;
+    memcpy(h.magic, kIndexMagic, 8); h.version = 2; h.block_bits = pl.block_bits; fill_header_params(sh, h);
+    r = device_hash(g, sh->d_graph, sh->nbytes, &h.stream_hash); if (r) return r;
+    h.nblk = pl.nblk;
+    const size_t nb = pl.nblk;
+    if (pl.h_maxd.size() != nb) return BVG_E_STATE;
     if (ix) { h.has_skip = 1; h.wide = ix->wide ? 1u : 0u; h.skip_lo = ix->blk_lo; h.skip_hi = ix->blk_hi; h.skip_total = ix->total; }
+    {   // payload checksum: the arrays in file order
+        uint64_t acc = 0, part = 0;
+        acc = fold_hash(acc, host_hash(pl.h_first.data(), (nb + 1) * 8), 1); acc = fold_hash(acc, host_hash(pl.h_maxd.data(), nb * 4), 2);
+        r = device_hash(g, pl.d_halo, nb * 4, &part); if (r) return r; acc = fold_hash(acc, part, 3);
+        r = device_hash(g, pl.d_mask, nb * 8, &part); if (r) return r; acc = fold_hash(acc, part, 4);
+        if (ix) {
+            acc = fold_hash(acc, host_hash(ix->h_first.data(), (nb + 1) * 8), 5); acc = fold_hash(acc, host_hash(ix->h_fmt.data(), nb), 6);
+            r = device_hash(g, ix->d_bit, ix->total * 2, &part); if (r) return r; acc = fold_hash(acc, part, 7);
+            r = device_hash(g, ix->d_val, ix->total * (ix->wide ? 8 : 4), &part); if (r) return r; acc = fold_hash(acc, part, 8);
+        }
+        h.payload_hash = acc;
+    }
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return BVG_E_IO;
     bool ok = fwrite(&h, sizeof h, 1, f) == 1;
-    const size_t nb = pl.nblk;
-    ok = ok && fwrite(pl.h_first.data(), 8, nb + 1, f) == nb + 1 && (pl.h_maxd.size() == nb) && fwrite(pl.h_maxd.data(), 4, nb, f) == nb;
+    ok = ok && fwrite(pl.h_first.data(), 8, nb + 1, f) == nb + 1 && fwrite(pl.h_maxd.data(), 4, nb, f) == nb;
     ok = ok && put_dev(f, pl.d_halo, nb * 4) && put_dev(f, pl.d_mask, nb * 8);
     if (ok && ix) {
         ok = fwrite(ix->h_first.data(), 8, nb + 1, f) == nb + 1 && fwrite(ix->h_fmt.data(), 1, nb, f) == nb;
@@ -1170,7 +1221,7 @@ static int save_index_impl(bvg_graph* g, const char* path) {
     return 0;
 }
 
-// BVG_E_IO: no such file / not an index of this graph (the caller then simply builds the index as usual)
+// BVG_E_IO: no such file / not an index of this graph / damaged (the caller then simply builds the index as usual)
 static int load_index_impl(bvg_graph* g, const char* path) {
     if (!g || !path) return BVG_E_ARG;
     Shared* sh = g->sh;
@@ -1178,38 +1229,71 @@ static int load_index_impl(bvg_graph* g, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return BVG_E_IO;
     struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
-    IndexHeader h{};
-    uint64_t fp = 0;
-    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kIndexMagic, 8) != 0 || h.version != 1) return BVG_E_IO;
-    int r = graph_fingerprint(sh, &fp); if (r) return r;
-    if (h.graph_bytes != sh->nbytes || h.total_bits != sh->total_bits || h.nodes != sh->p.nodes || h.window != (uint32_t)sh->p.window_size || h.fingerprint != fp ||
-        h.block_bits != block_bits_of(g) || h.nblk == 0 || (uint64_t)h.nblk > (uint64_t)sh->p.nodes) return BVG_E_IO;
+    IndexHeader h{}, want{};
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, kIndexMagic, 8) != 0 || h.version != 2) return BVG_E_IO;
+    fill_header_params(sh, want);
+    if (h.graph_bytes != want.graph_bytes || h.total_bits != want.total_bits || h.nodes != want.nodes || h.window != want.window || h.min_interval != want.min_interval ||
+        h.zeta_k != want.zeta_k || h.cod_outdegree != want.cod_outdegree || h.cod_block != want.cod_block || h.cod_residual != want.cod_residual ||
+        h.cod_reference != want.cod_reference || h.cod_block_count != want.cod_block_count || h.skip_min != want.skip_min || h.skip_every != want.skip_every ||
+        h.block_bits != block_bits_of(g) || h.nblk == 0 || (uint64_t)h.nblk > (uint64_t)sh->p.nodes || h.wide > 1u || h.has_skip > 1u) return BVG_E_IO;
+    // sizes first: the file must hold exactly what the header promises (and the entry count must be one the stream could produce)
     const size_t nb = h.nblk;
+    if (h.has_skip && (h.skip_lo >= h.skip_hi || h.skip_hi > h.nblk || h.skip_total > sh->total_bits)) return BVG_E_IO;
+    {
+        const uint64_t vb = h.wide ? 8 : 4;
+        uint64_t want_bytes = sizeof h + (uint64_t)(nb + 1) * 8 + (uint64_t)nb * 4 + (uint64_t)nb * 4 + (uint64_t)nb * 8;
+        if (h.has_skip) want_bytes += (uint64_t)(nb + 1) * 8 + nb + h.skip_total * 2 + h.skip_total * vb;
+        if (fseek(f, 0, SEEK_END) != 0) return BVG_E_IO;
+        const long long fsz = ftell(f);
+        if (fsz < 0 || (uint64_t)fsz != want_bytes || fseek(f, (long)sizeof h, SEEK_SET) != 0) return BVG_E_IO;
+    }
+    {   // every byte of the stream, hashed on the device: a .graph rewritten in place with the same size is not this index's graph
+        uint64_t sh_hash = 0;
+        int r = device_hash(g, sh->d_graph, sh->nbytes, &sh_hash); if (r) return r;
+        if (sh_hash != h.stream_hash) return BVG_E_IO;
+    }
     std::shared_ptr<Plan> np = std::make_shared<Plan>();
     Plan& pl = *np;
     pl.device = sh->device; pl.block_bits = h.block_bits; pl.nblk = h.nblk; pl.h_first.resize(nb + 1); pl.h_maxd.resize(nb);
     if (fread(pl.h_first.data(), 8, nb + 1, f) != nb + 1 || fread(pl.h_maxd.data(), 4, nb, f) != nb) return BVG_E_IO;
     if (pl.h_first[0] != 0 || pl.h_first[nb] != (uint64_t)sh->p.nodes) return BVG_E_IO;
     for (size_t i = 0; i < nb; i++) if (pl.h_first[i] >= pl.h_first[i + 1]) return BVG_E_IO;
+    uint64_t acc = 0, part = 0;
+    acc = fold_hash(acc, host_hash(pl.h_first.data(), (nb + 1) * 8), 1); acc = fold_hash(acc, host_hash(pl.h_maxd.data(), nb * 4), 2);
     if (hipMalloc(&pl.d_first, (nb + 1) * 8) != hipSuccess || hipMalloc(&pl.d_halo, nb * 4) != hipSuccess || hipMalloc(&pl.d_mask, nb * 8) != hipSuccess) { (void)hipGetLastError(); return BVG_E_NOMEM; }
     HIPCHK(hipMemcpy(pl.d_first, pl.h_first.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
-    if (!get_dev(f, pl.d_halo, nb * 4) || !get_dev(f, pl.d_mask, nb * 8)) return BVG_E_IO;
+    {   // halos: range-checked on the host on their way in (a halo reaches at most kMaxHalo nodes back and never before node 0)
+        std::vector<uint32_t> halo(nb);
+        if (fread(halo.data(), 4, nb, f) != nb) return BVG_E_IO;
+        for (size_t i = 0; i < nb; i++) if (halo[i] > (uint32_t)kMaxHalo || (uint64_t)halo[i] > pl.h_first[i]) return BVG_E_IO;
+        HIPCHK(hipMemcpy(pl.d_halo, halo.data(), nb * 4, hipMemcpyHostToDevice));
+        acc = fold_hash(acc, host_hash(halo.data(), nb * 4), 3);
+    }
+    if (!get_dev(f, pl.d_mask, nb * 8)) return BVG_E_IO;
+    { int r = device_hash(g, pl.d_mask, nb * 8, &part); if (r) return r; acc = fold_hash(acc, part, 4); }
+    std::shared_ptr<SkipIndex> ix;
     if (h.has_skip) {
-        if (h.skip_lo >= h.skip_hi || h.skip_hi > h.nblk) return BVG_E_IO;
-        std::shared_ptr<SkipIndex> ix = std::make_shared<SkipIndex>();
-        ix->device = sh->device; ix->blk_lo = h.skip_lo; ix->blk_hi = h.skip_hi; ix->total = h.skip_total; ix->wide = h.wide != 0;
+        ix = std::make_shared<SkipIndex>();
+        ix->device = sh->device; ix->blk_lo = h.skip_lo; ix->blk_hi = h.skip_hi; ix->total = h.skip_total; ix->wide = h.wide != 0; ix->gen = next_plan_version();
         ix->h_first.resize(nb + 1); ix->h_fmt.resize(nb);
         if (fread(ix->h_first.data(), 8, nb + 1, f) != nb + 1 || fread(ix->h_fmt.data(), 1, nb, f) != nb) return BVG_E_IO;
-        if (ix->h_first[nb] != ix->total) return BVG_E_IO;
-        for (size_t i = 0; i < nb; i++) if (ix->h_first[i] > ix->h_first[i + 1]) return BVG_E_IO;
+        if (ix->h_first[0] != 0 || ix->h_first[nb] != ix->total) return BVG_E_IO;
+        for (size_t i = 0; i < nb; i++) {
+            if (ix->h_first[i] > ix->h_first[i + 1] || ix->h_fmt[i] > 3) return BVG_E_IO;
+            if ((i < ix->blk_lo || i >= ix->blk_hi) && (ix->h_first[i] != ix->h_first[i + 1] || ix->h_fmt[i] != 0)) return BVG_E_IO;   // nothing outside the indexed blocks
+        }
+        acc = fold_hash(acc, host_hash(ix->h_first.data(), (nb + 1) * 8), 5); acc = fold_hash(acc, host_hash(ix->h_fmt.data(), nb), 6);
         const size_t vb = ix->wide ? 8 : 4;
         if (hipMalloc(&ix->d_first, (nb + 1) * 8) != hipSuccess || hipMalloc(&ix->d_bit, (size_t)ix->total * 2 + 16) != hipSuccess || hipMalloc(&ix->d_fmt, nb) != hipSuccess ||
             hipMalloc(&ix->d_val, (size_t)ix->total * vb + 16) != hipSuccess) { (void)hipGetLastError(); return BVG_E_NOMEM; }
         HIPCHK(hipMemcpy(ix->d_first, ix->h_first.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(ix->d_fmt, ix->h_fmt.data(), nb, hipMemcpyHostToDevice));
         if (!get_dev(f, ix->d_bit, (size_t)ix->total * 2) || !get_dev(f, ix->d_val, (size_t)ix->total * vb)) return BVG_E_IO;
-        std::atomic_store(&pl.skip, ix);
+        int r = device_hash(g, ix->d_bit, ix->total * 2, &part); if (r) return r; acc = fold_hash(acc, part, 7);
+        r = device_hash(g, ix->d_val, ix->total * vb, &part); if (r) return r; acc = fold_hash(acc, part, 8);
     }
+    if (acc != h.payload_hash) return BVG_E_IO;                              // bit rot, truncation that kept the size, an edited file
+    if (ix) std::atomic_store(&pl.skip, ix);
     pl.version = next_plan_version();
     std::lock_guard<std::mutex> lk(sh->mu);
     sh->plans.clear(); sh->plans[pl.block_bits] = np;
@@ -1434,7 +1518,7 @@ static int dr_ensure(bvg_graph* g, size_t bytes) {
 static int decode_range_impl(bvg_graph* g, int64_t from, int64_t to, int32_t* outdeg, int64_t* succ, uint64_t cap, uint64_t* n_succ, bool dev, bool narrow = false) {
     if (!g) return BVG_E_ARG;
     Shared* sh = g->sh;
-    if (narrow && (dev || (uint64_t)sh->p.nodes + g->node_base > (1ull << 32))) return BVG_E_UNSUPPORTED;   // 32-bit ids: host path, every id below 2^32
+    if (narrow && (dev || (uint64_t)sh->p.nodes + g->node_base > 0xFFFFFFFFull)) return BVG_E_UNSUPPORTED;   // 32-bit ids: host path, every id below 2^32 - 1 (0xFFFFFFFF stands for the -1 of a malformed stream, never for a node)
     if (from < 0 || to > sh->p.nodes || from > to) return BVG_E_ARG;               // BVG:863,1000,1128
     if (from == to) { if (n_succ) *n_succ = 0; return 0; }
     HIPCHK(hipSetDevice(sh->device));
@@ -1838,7 +1922,7 @@ static int bvg_build_index_impl(bvg_graph* g, int64_t from, int64_t to, uint64_t
     const std::vector<uint64_t>& hf = plp->h_first;
     uint32_t lo = (uint32_t)(std::upper_bound(hf.begin(), hf.end(), (uint64_t)from) - hf.begin()); lo = lo ? lo - 1 : 0;
     uint32_t hi = (uint32_t)(std::lower_bound(hf.begin(), hf.end(), (uint64_t)to) - hf.begin()); if (hi > plp->nblk) hi = plp->nblk;
-    if (hi > lo) { r = build_skip(g, plp, lo, hi); if (r) return r; }
+    if (hi > lo) { r = build_skip(g, plp, lo, hi, /*retry_failed=*/true); if (r) return r; }
     std::shared_ptr<SkipIndex> ix = std::atomic_load(&plp->skip);
     if (ix) {
         if (entries) *entries = ix->total;

@@ -20,6 +20,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 
 namespace bvg {
@@ -352,6 +353,14 @@ int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, in
     launch_walk(nullptr, nchunks, true);                                 // round 0: every chunk from its guess
     int rounds = 1;
     const int max_rounds = 1 << 22;
+    // Rounds are bounded by PROGRESS and by TIME, not only by count: a region that settles one 4 KiB chunk per round would make the
+    // rounds O(chunks) -- each with a detection pass over all chunks and two host syncs, quadratic in the stream -- before the caller
+    // falls back to the sequential walk anyway.  Give up (-3) when the first mismatching chunk advanced by fewer than kSlowStep chunks
+    // per round over the last kSlowRounds rounds, or when the rounds have used their time budget (30 s + 20 s per GiB of stream).
+    constexpr uint32_t kSlowRounds = 256, kSlowStep = 2;
+    uint32_t mark_round = 0, mark_first = 0;
+    const auto t_start = std::chrono::steady_clock::now();
+    const double budget_s = 30.0 + 20.0 * (double)nbytes / (double)(1ull << 30);
     for (;;) {
         const uint32_t init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
         if (hipMemcpyAsync(d_n, init, 16, hipMemcpyHostToDevice, s) != hipSuccess) return -2;
@@ -360,6 +369,14 @@ int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, in
         if (hipMemcpyAsync(h, d_n, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -2;
         if (h[0] == 0) break;                                            // every chunk enters where its predecessor left: the one true walk
         if (rounds >= max_rounds) return -3;
+        if ((uint32_t)rounds - mark_round >= kSlowRounds) {
+            if (h[1] - mark_first < kSlowRounds * kSlowStep && rounds > (int)kSlowRounds) {
+                if (dbg_on()) fprintf(stderr, "[bvg] derive: %u rounds moved the first unsettled chunk from %u to %u of %u: giving up on the parallel walk\n", kSlowRounds, mark_first, h[1], nchunks);
+                return -3;
+            }
+            mark_round = (uint32_t)rounds; mark_first = h[1];
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > budget_s) return -3;
+        }
         hipLaunchKernelGGL(derive_adopt_kernel, dim3((h[0] + 255) / 256), dim3(256), 0, s, R, entry, entry_ring, exitst, exit_ring, mis_list, d_n, walk_list, d_n + 2);
         uint32_t nw = 0;
         if (hipMemcpyAsync(&nw, d_n + 2, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return -2;

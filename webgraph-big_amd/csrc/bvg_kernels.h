@@ -134,6 +134,8 @@ void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool 
 
 // sums the result stripes into stripe 0 (one workgroup)
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);
+// *out += position-keyed 64-bit hash of the nbytes at p (device memory, 8-byte aligned); *out must be zeroed by the caller
+void launch_hash_words(const void* p, uint64_t nbytes, unsigned long long* out, hipStream_t s);
 // thread per node: outdegree (BVG:821-842)
 void launch_outdegrees(const uint8_t* graph, uint64_t limit_byte, Offsets offsets, int64_t from, int64_t to,
                        int outdegree_coding, int32_t* out, unsigned long long* total, hipStream_t s);

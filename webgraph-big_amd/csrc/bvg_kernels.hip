@@ -633,6 +633,34 @@ __global__ void __launch_bounds__(256) reduce_acc_kernel(unsigned long long* acc
         acc[3] = part[0][3] | part[1][3] | part[2][3] | part[3][3];
     }
 }
+// 64-bit hash of a device array: the sum, mod 2^64, of a position-keyed mix of its 8-byte words (the tail bytes packed into one more
+// word).  Order-free, so a grid-stride pass at memory speed; ties the index on disk (bvg_save_index) to EVERY byte of the stream it was
+// built from, and guards the index payload itself against bit rot.
+__global__ void __launch_bounds__(256) hash_words_kernel(const uint8_t* p, uint64_t nbytes, unsigned long long* out) {
+    const uint64_t nw = nbytes >> 3;
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(p);
+    uint64_t h = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t z = w[i] + (i + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
+        h += z;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (nbytes & 7)) {
+        uint64_t t = 0;
+        for (uint64_t b = nw << 3; b < nbytes; b++) t = (t << 8) | p[b];
+        uint64_t z = t + (nw + 1) * 0x9E3779B97F4A7C15ull + (nbytes & 7);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
+        h += z;
+    }
+    h = wave_sum64(h);
+    if ((threadIdx.x & 63u) == 0 && h) atomicAdd(out, (unsigned long long)h);
+}
+void launch_hash_words(const void* p, uint64_t nbytes, unsigned long long* out, hipStream_t s) {
+    const uint64_t nw = nbytes >> 3;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((nw + 255) / 256, 1), 256u * 32u);
+    hipLaunchKernelGGL(hash_words_kernel, dim3(blocks), dim3(256), 0, s, (const uint8_t*)p, nbytes, out);
+}
+
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s) {
     hipLaunchKernelGGL(reduce_acc_kernel, dim3(1), dim3(256), 0, s, acc, stripes);
 }

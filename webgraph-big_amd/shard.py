@@ -42,6 +42,16 @@ def allreduce_max(value, device=None, group=None):
     return float(t.item())
 
 
+def allgather_float(value, rank, world, device=None, group=None):
+    """Every rank's value, in rank order (a sum all-reduce of a vector with one slot per rank: works on every backend)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[rank] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return [float(v) for v in t.cpu().tolist()]
+
+
 def bounds_by_arcs(outdeg, k):
     """The rule of bvg_split_by_arcs on a host array of outdegrees: bounds[j] = first node whose cumulative outdegree (exclusive
     prefix) reaches j * ceil(arcs / k) (the skipTo() targets of algo/HyperBall.java:748-768); bounds[0] = 0, bounds[k] = n."""
