@@ -13,11 +13,14 @@ n = g.num_nodes(); arcs = st.stats['arcs'] * K
 d_deg = torch.empty(n, dtype=torch.int32, device='cuda'); d_succ = torch.empty(arcs, dtype=torch.int64, device='cuda')
 need = C.c_uint64()
 L = W.lib()
-for it in range(3):
+times = []
+for it in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     st_ = L.bvg_decode_range_dev(g._h, 0, n, d_deg.data_ptr(), d_succ.data_ptr(), arcs, C.byref(need))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     assert st_ == 0 and need.value == arcs, (st_, need.value, arcs)
+    times.append(dt)
+dt = min(times[2:])                                                   # (the first call builds the index, the second learns the tiers)
 print(shape, 'materialise %d arcs in %.1f ms -> %.1f G edges/s, %.1f GB/s written' % (arcs, dt * 1e3, arcs / dt / 1e9, arcs * 8 / dt / 1e9))
 # spot check vs first tile through the host path
 deg, succ = base.decode_range(0, 1000)

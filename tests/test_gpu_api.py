@@ -326,15 +326,16 @@ def test_successors_as_32_bit_ids_for_the_host_path(W, small, oracle):
     od, os_ = og.decode_range(n // 3, n // 2)
     assert np.array_equal(d32, od) and np.array_equal(s32, os_)
     h = g.copy()
-    h.set_node_base((1 << 32) - n)                                      # the largest base that still fits
+    top = (1 << 32) - 1 - n                                             # the largest base that still fits: every id stays BELOW 0xFFFFFFFF, which stands for -1
+    h.set_node_base(top)
     _, s32 = h.decode_range32(0, 100)
-    assert np.array_equal(s32.astype(np.int64), og.decode_range(0, 100)[1] + ((1 << 32) - n))
-    h.set_node_base((1 << 32) - n + 1)
+    assert np.array_equal(s32.astype(np.int64), og.decode_range(0, 100)[1] + top) and int(s32.max()) < 0xFFFFFFFF
+    h.set_node_base(top + 1)
     with pytest.raises(W.UnsupportedOperationException):
         h.decode_range32(0, 100)
-    it = W.NodeIterator(h, 0, batch_nodes=512)                          # beyond 2^32 the iterator moves int64
+    it = W.NodeIterator(h, 0, batch_nodes=512)                          # beyond it the iterator moves int64
     it.next_long()
-    assert it.successor_array().dtype == np.int64 and np.array_equal(it.successor_array(), og.successors(0) + ((1 << 32) - n + 1))
+    assert it.successor_array().dtype == np.int64 and np.array_equal(it.successor_array(), og.successors(0) + (top + 1))
     it.close(); h.close()
     it = W.NodeIterator(g, 5, batch_nodes=300)                          # below: uint32 batches, widened per node
     x = it.next_long()

@@ -12,7 +12,7 @@ from bvrecords import Record, assemble
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL", "BVG_SCAN_WAVES", "BVG_GIANT", "BVG_WIDE_HALF", "BVG_NO_LISTCUT")
+KNOBS = ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_SCANK", "BVG_SCAN_POOL", "BVG_SCAN_WAVES", "BVG_GIANT", "BVG_WIDE_HALF", "BVG_NO_LISTCUT", "BVG_MAT_LEAN", "BVG_NO_D2", "BVG_DEBUG")
 
 
 @pytest.fixture(autouse=True)
@@ -299,3 +299,106 @@ def test_plan_cuts_blocks_around_large_lists(W, tools, oracle, monkeypatch):
         assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), cut
         g.close()
     assert blocks[True] > blocks[False], blocks
+
+
+# ---- the materialising form of the scan kernel (scan_kernel<..., MAT = true>): what backs nodeIterator() / successorBigArray()
+# (BVGraph.java:1164-1176, SpeedTest.java:127-135) once the index exists ----------------------------------------------------------------
+def _lean_blocks_of_last_decode(err):
+    import re
+    m = [l for l in err.splitlines() if "tiers concurrent" in l]
+    assert m, err[-2000:]
+    k = re.search(r"scan kernel (\d+) \+ (\d+)/(\d+)/(\d+)/(\d+) LDS-class", m[-1])
+    return sum(int(v) for v in k.groups())
+
+
+@pytest.mark.parametrize("shape", ["eu", "eu_dense", "web", "w0", "heavy_tail", "intervals", "no_d2"])
+def test_materialising_scan_kernel_matches_oracle(W, tools, oracle, monkeypatch, capfd, shape):
+    """Every list of every node, bit for bit, out of the lean kernel: lists that are copied from and lists without reference built in
+    LDS and copied out, leaves with a reference merged straight into the output (MaskedLongIterator.java:73-100 + the extras, placed
+    by position); whole graph, sub-ranges that cut blocks, a node base, a flyweight."""
+    monkeypatch.setenv("BVG_DEBUG", "1"); monkeypatch.setenv("BVG_MAT_LEAN", "1")   # (sparse graphs materialise on the row kernel by default: here the lean kernel takes every shape)
+    kw, synth, n = {}, None, 40000
+    if shape == "eu": synth = tools.eu_like()
+    if shape == "eu_dense": synth = tools.eu_like(mean_deg=127.5)
+    if shape == "web": synth = tools.web_like(mean_deg=30.0)
+    if shape == "w0": synth, kw = tools.web_like(mean_deg=40.0), dict(window_size=0, max_ref_count=0, min_interval_length=0)
+    if shape == "heavy_tail": synth, n = tools.eu_like(max_deg=30000, tail_alpha=1.6, mean_deg=40.0), 15000
+    if shape == "intervals": synth, kw = tools.eu_like(p_interval=0.9, interval_len=40.0), dict(min_interval_length=2)
+    if shape == "no_d2": synth = tools.eu_like(p_interval=0.8); monkeypatch.setenv("BVG_NO_D2", "1")   # reference-free lists with intervals through the position tasks
+    st = tools.synth_store(n, seed=47, params=W.default_params(**kw), synth=synth, threads=4)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    og = _og(oracle, st)
+    odeg, osucc = og.decode_range(0, n)
+    g.build_index()
+    for rnd in range(2):                                               # (learned tiers settle after the first call)
+        capfd.readouterr()
+        deg, succ = g.decode_range(0, n)
+        lean = _lean_blocks_of_last_decode(capfd.readouterr().err)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), (shape, rnd)
+    assert lean > 0, "the materialising call did not run the lean kernel"
+    cum = np.concatenate([[0], np.cumsum(odeg, dtype=np.int64)])
+    rng = np.random.default_rng(9)
+    for _ in range(10):
+        a, b = sorted(int(v) for v in rng.integers(0, n + 1, 2))
+        if b - a < 4096: b = min(n, a + 4096 + int(rng.integers(0, 3000)))   # (shorter ranges run index-less on the row kernel: other tests)
+        d1, s1 = g.decode_range(a, b)
+        assert np.array_equal(d1, odeg[a:b]) and np.array_equal(s1, osucc[cum[a]:cum[b]]), (shape, a, b)
+    g.set_node_base((1 << 33) + 5)
+    d1, s1 = g.decode_range(n // 4, n)
+    assert np.array_equal(s1, osucc[cum[n // 4]:] + ((1 << 33) + 5))
+    g.set_node_base(0)
+    h = g.copy()
+    d1, s1 = h.decode_range(0, n // 2)
+    assert np.array_equal(s1, osucc[:cum[n // 2]])
+    it = W.NodeIterator(h, n // 3, batch_nodes=8192)                    # the iterator's batches ride on it too
+    for x in range(n // 3, n // 3 + 9000):
+        assert it.next_long() == x
+        assert np.array_equal(it.successor_array(), osucc[cum[x]:cum[x + 1]]), x
+    it.close(); h.close(); g.close()
+
+
+@pytest.mark.parametrize("pool", ["640", "1024", "3072"])
+def test_materialising_scan_kernel_pool_sizes(W, tools, oracle, monkeypatch, pool):
+    """Sub-rows cut short by the pool (the parked residuals of the leaves count in MAT mode), blocks failing over to the row kernel."""
+    monkeypatch.setenv("BVG_SCAN_POOL", pool); monkeypatch.setenv("BVG_MAT_LEAN", "1")
+    st = tools.synth_store(30000, seed=49, synth=tools.eu_like(mean_deg=100.0), threads=4)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    odeg, osucc = _og(oracle, st).decode_range(0, 30000)
+    g.build_index()
+    for _ in range(2):
+        deg, succ = g.decode_range(0, 30000)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), pool
+    g.close()
+
+
+def test_materialising_scan_kernel_on_wide_graphs(W, tools, oracle, monkeypatch, capfd):
+    """force_wide: 32-bit lists of ids relative to the block's base, the base added back on the way out."""
+    monkeypatch.setenv("BVG_DEBUG", "1"); monkeypatch.setenv("BVG_MAT_LEAN", "1")
+    st = tools.synth_store(30000, seed=51, synth=tools.eu_like(mean_deg=60.0), threads=4)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    g.set_tuning(force_wide=True)
+    odeg, osucc = _og(oracle, st).decode_range(0, 30000)
+    g.build_index()
+    for _ in range(2):
+        capfd.readouterr()
+        deg, succ = g.decode_range(0, 30000)
+        lean = _lean_blocks_of_last_decode(capfd.readouterr().err)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc)
+    assert lean > 0
+    g.set_node_base((1 << 40) + 3)
+    assert np.array_equal(g.decode_range(100, 29000)[1], osucc[np.cumsum(odeg, dtype=np.int64)[99]:np.cumsum(odeg, dtype=np.int64)[28999]] + ((1 << 40) + 3))
+    g.close()
+
+
+def test_cnr2000_materialised_by_the_lean_kernel_matches_the_golden(W, cnr_csr, monkeypatch, capfd):
+    """BVGraphTest.testLarge through the materialising lean kernel (the reference's own expected lists)."""
+    from conftest import CNR
+    monkeypatch.setenv("BVG_DEBUG", "1"); monkeypatch.setenv("BVG_MAT_LEAN", "1")
+    g = W.BVGraph.load(CNR)
+    g.build_index()
+    capfd.readouterr()
+    deg, succ = g.decode_range(0, g.num_nodes())
+    lean = _lean_blocks_of_last_decode(capfd.readouterr().err)
+    gdeg, gsucc = cnr_csr
+    assert np.array_equal(deg, gdeg) and np.array_equal(succ, gsucc) and lean > 0
+    g.close()

@@ -207,23 +207,37 @@ def test_oracle_treats_a_negative_residual_count_as_none(W, oracle, lead, pad):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", sorted(MODES))
-def test_hip_treats_a_negative_residual_count_as_the_oracle_does(W, oracle, monkeypatch, mode):
+def test_hip_refuses_a_negative_residual_count(W, oracle, monkeypatch, mode):
+    """The other side of the deviation: the HIP path does NOT guess.  A record whose counts contradict each other is a malformed file
+    (bounded, not bit-exact): every call whose node range holds such a record ends with EOFException (BVG_E_EOF, the
+    ERR_MALFORMED bit) in every tier -- never a hang (the Java's iterator would not stop), never a silently different list -- while
+    ranges that do not touch it decode exactly."""
     for k in ("BVG_EMIT", "BVG_DBG", "BVG_NOSKIP", "BVG_GIANT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
     for lead, pad in [(0, 0), (5, 80), (70, 3), (0, 5000)]:
         p, g, offs, lists = _negative_count_graph(W, lead, pad)
-        og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), g.tobytes(), offs)
         hg = W.BVGraph.from_memory(p, g, offs)
-        for _ in range(2):                                    # (the second scan of the large case runs indexed: the odd blocks must not reach the lean kernel)
-            o, r = og.scan(), hg.scan()
-            assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), (mode, lead, pad)
-        deg, succ = hg.decode_range(0, p.nodes)
-        assert deg.tolist() == [len(l) for l in lists]
-        assert succ.tolist() == [v for l in lists for v in l], (mode, lead, pad)
+        for _ in range(2):                                    # (twice: the second scan of the large case would run indexed)
+            with pytest.raises(W.EOFException):
+                hg.scan()
+        with pytest.raises(W.EOFException):
+            hg.decode_range(0, p.nodes)
         for x in (lead + 1, lead + 3):
-            assert hg.decode_range(x, x + 1)[1].tolist() == lists[x]
-        sb = hg.successors_batch(np.array([lead + 3, lead + 1], dtype=np.int64))
-        assert sb[1].tolist() == lists[lead + 3] + lists[lead + 1]
+            with pytest.raises(W.EOFException):
+                hg.decode_range(x, x + 1)
+            with pytest.raises(W.EOFException):
+                hg.successors_batch(np.array([x], dtype=np.int64))
+        # everything that does not touch the two odd records is exact: the nodes before them, their (well-formed) referenced lists, the nodes behind
+        flat = lambda a, b: [v for l in lists[a:b] for v in l]
+        if lead:
+            assert hg.decode_range(0, lead)[1].tolist() == flat(0, lead)
+        assert hg.decode_range(lead, lead + 1)[1].tolist() == lists[lead] and hg.decode_range(lead + 2, lead + 3)[1].tolist() == lists[lead + 2]
+        if pad > 8:
+            a0 = lead + 4 + 8                                     # (W = 7 nodes behind the odd ones: no reference reaches them)
+            assert hg.decode_range(a0, p.nodes)[1].tolist() == flat(a0, p.nodes)
+            og = oracle.Graph.from_memory(oracle.Params(**p.as_dict()), g.tobytes(), offs)
+            r, o = hg.scan(a0, p.nodes), og.scan(a0, p.nodes)
+            assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"])
         hg.close()

@@ -687,7 +687,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         {
             const Codings& c = a.cod;
             const bool dflt = c.outdegree == BVG_GAMMA && c.reference == BVG_UNARY && c.block_count == BVG_GAMMA && c.block == BVG_GAMMA && c.residual == BVG_ZETA;
-            fast_ok = predict && !materialise && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default && a.skip_first && a.skip_fmt && skx &&
+            // (a materialising call takes it on dense graphs only: below ~16 arcs per node the row kernel's pipelined loop is the faster way to
+            //  build every list -- web shape 71.9 vs 60.5 G edges/s, eu shape 93.6 vs 165.9: profiles/r04_mat_first.txt)
+            fast_ok = predict && !(materialise && avg < 16.0 && !knob("BVG_MAT_LEAN")) && dflt && a.emit_tasks && g->skip_mode == 0 && rows_default && a.skip_first && a.skip_fmt && skx &&
                       skx->h_fmt.size() == pl.nblk && !wg_nw && !flow && !(knob("BVG_SCANK") && atoi(knob("BVG_SCANK")) == 0);
             if (fast_ok) {
                 // LDS per wavefront: pool (stored lists + their parked residuals + the window) + scratch (copy blocks, intervals, run
@@ -706,7 +708,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
                 for (uint64_t w : {24ull, 20ull, 16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
-                    if (w > 16 && wforce != w && !(w == 24 && avg <= 16.0 && sh->p.window_size > 0 && !wforce)) continue;   // more than 16: the 85-VGPR instantiation, sparse graphs with references only (web shape: +7 %; eu15: -11 % at 20; w0, all residuals: -6 %)
+                    if (w > 16 && wforce != w && !(w == 24 && avg <= 16.0 && sh->p.window_size > 0 && !wforce && !materialise)) continue;   // more than 16: the 85-VGPR instantiation, sparse graphs with references only (web shape: +7 %; eu15: -11 % at 20; w0, all residuals: -6 %)
                     if (wforce && w != wforce && w != 4) continue;
                     uint64_t pw = 8192;
                     while (pw > 512 && lds_cu / foot(pw, w) < w) pw -= 32;
@@ -807,7 +809,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
             auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
-            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 16, g->stream); launches++; alone(g->stream); }
+            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 16, materialise, g->stream); launches++; alone(g->stream); }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
@@ -831,10 +833,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (!pd.count[7 + c]) continue;
                 DecodeArgs ac = af; ac.work_list = pd.d_lists + offc[7 + c];
                 ac.lds_pool_elems = lclasses[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, lclasses[c - 1] / 4); ac.lds_stage_words = 1024;
-                launch_scan_decode(ac, pd.count[7 + c], wide, false, side_of(c)); alone(side_of(c));
+                if (knob("BVG_CLASS_STAGE")) { unsigned v[4] = {1024, 1024, 1024, 1024}; sscanf(knob("BVG_CLASS_STAGE"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_stage_words = std::min(2048u, std::max(128u, v[c - 1] & ~3u)); }   // experiments: the classes' LDS geometry
+                if (knob("BVG_CLASS_SCR")) { unsigned v[4] = {1024, 1024, 2048, 3072}; sscanf(knob("BVG_CLASS_SCR"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_scr_elems = std::min(8192u, std::max(128u, v[c - 1])); }
+                launch_scan_decode(ac, pd.count[7 + c], wide, false, materialise, side_of(c)); alone(side_of(c));
                 launches++;
             }
-            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 16, g->stream); launches++; alone(g->stream); }
+            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 16, materialise, g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));

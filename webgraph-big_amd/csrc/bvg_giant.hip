@@ -743,15 +743,19 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
 
 // scan / materialise the blocks of the work list with one 1024-thread workgroup each; a.gpool / a.gscr: per-workgroup areas as for
 // decode_kernel<SLOW>.  Default codings and windows <= kMaxWindow only (the caller checks).
+static const size_t giant_pad_default = 0;
 void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s) {
     if (nblocks == 0) return;
     dim3 grid(nblocks), block(GNT);
+    // unused LDS per workgroup (experiments): with > 70 KB only ONE giant workgroup fits a CU, which leaves wave slots and registers for the
+    // wavefronts of tier 0 launched beside it
+    const size_t pad = knob("BVG_GIANT_PAD") ? (size_t)std::min(140000, std::max(0, atoi(knob("BVG_GIANT_PAD")))) : giant_pad_default;
     if (wide) {
-        if (materialise) hipLaunchKernelGGL((giant_kernel<uint64_t, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((giant_kernel<uint64_t, false>), grid, block, 0, s, a);
+        if (materialise) hipLaunchKernelGGL((giant_kernel<uint64_t, true>), grid, block, pad, s, a);
+        else hipLaunchKernelGGL((giant_kernel<uint64_t, false>), grid, block, pad, s, a);
     } else {
-        if (materialise) hipLaunchKernelGGL((giant_kernel<uint32_t, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((giant_kernel<uint32_t, false>), grid, block, 0, s, a);
+        if (materialise) hipLaunchKernelGGL((giant_kernel<uint32_t, true>), grid, block, pad, s, a);
+        else hipLaunchKernelGGL((giant_kernel<uint32_t, false>), grid, block, pad, s, a);
     }
 }
 

@@ -123,7 +123,11 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
 // NBZ: the node base is 0 (no carry handling in the checksum key); Z3: zeta_3 residuals (the specialised decoder)
 // OCC: wavefronts per SIMD the register allocation leaves room for -- 4 (128 VGPRs: nothing spills, 16 wavefronts per CU) or 6 (85 VGPRs, a
 // handful of spills, 24 per CU: sparse graphs, whose lists need little LDS, gain 9 % from the extra wavefronts; profiles/r03_ab_w20.txt)
-template <bool NBZ, bool Z3, bool WIDE, int OCC, bool D2>
+// MAT: the materialising form behind nodeIterator() / successorBigArray() (BVG:1164-1176, a.succ / a.cum / a.outdeg): every list of a reported
+// node is written to the output -- lists that are copied from and lists without reference are built in LDS exactly as in scan mode and copied
+// out in coalesced runs; a LEAF with a reference (most nodes) is merged straight into the output by the same position tasks (its parked
+// residuals and its block / interval entries are all it needs of LDS); nothing is summed (no checksum: the caller gets the arcs).
+template <bool NBZ, bool Z3, bool WIDE, int OCC, bool D2, bool MAT>
 __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
@@ -474,15 +478,21 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             for (uint32_t j = 0; j < W && j < 64; j++) { const uint32_t t = lane_get(tgt, j); if (t < 64) refmask |= 1ull << t; }
         }
         BVG_T1(15, tqp);
-        const bool stored = (refmask >> lane) & 1ull;
-        BVG_WC(12, __popcll(ballot(stored && on1)));                          // (work-count build: stored lists | reference-free with intervals | with reference and extras | direct)
-        BVG_WC(13, __popcll(ballot(stored && on1 && ref == 0 && ic != 0)));
-        BVG_WC(9, __popcll(ballot(stored && on1 && ref != 0 && (ic != 0 || nres != 0))));
-        BVG_WC(14, __popcll(ballot(stored && on1 && ref == 0 && ic == 0)));
+        const bool copied_from = (refmask >> lane) & 1ull;
+        BVG_WC(12, __popcll(ballot(copied_from && on1)));                     // (work-count build: stored lists | reference-free with intervals | with reference and extras | direct)
+        BVG_WC(13, __popcll(ballot(copied_from && on1 && ref == 0 && ic != 0)));
+        BVG_WC(9, __popcll(ballot(copied_from && on1 && ref != 0 && (ic != 0 || nres != 0))));
+        BVG_WC(14, __popcll(ballot(copied_from && on1 && ref == 0 && ic == 0)));
         const bool repn = on1 && x >= rep_lo && x < rep_hi;
+        // MAT: a reported list WITHOUT reference is built in the pool like a stored one (it is decoded straight into place: the cheap path) and
+        // copied out; a reported leaf WITH a reference (gl) is merged straight into the output by the position tasks
+        const bool stored = copied_from || (MAT && repn && ref == 0 && d > 0);
+        const bool gl = MAT && repn && !stored && d > 0;
+        uint64_t gofs = 0;                                                    // where the node's successors go in a.succ
+        if (MAT && repn) gofs = a.cum[x - a.from];
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
         uint32_t k0 = 0, k1 = 0;
-        if (repn) {
+        if (repn && !MAT) {
             const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
             k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
         }
@@ -528,7 +538,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             const uint32_t avail = CAPe - pool_used;
             const bool cand = on1 && lane >= sa;
             const uint32_t size = (cand && stored) ? dclamp : 0u;
-            const uint32_t rsz = (cand && stored && !direct && !d2) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks
+            const uint32_t rsz = (cand && (stored || gl) && !direct && !d2) ? (nres >= CAP ? CAP + 1 : nres + 1u) : 0u;     // parked residuals + the guard slot of the position tasks (MAT: also those of the leaves merged into the output)
             const uint32_t sincl = wave_incl_scan32(size), rincl = wave_incl_scan32(rsz);
             const bool fits = lane >= sa && lane < K1 && (uint64_t)sincl + rincl <= avail;
             const uint32_t se = sa + (uint32_t)__popcll(ballot(fits));          // (the sums are prefixes: `fits` is a contiguous run from sa)
@@ -588,7 +598,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64), s_ce = (uint32_t)__shfl((int)ce, nl, 64);
                         const uint32_t q = tl[u] ? (isl ? t - s_ts : s_ce) : 0u;
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
-                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? ((direct || d2) ? base : rtb) : kInf, nl, 64), t_ef = __shfl(efirst, nl, 64);
+                        const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? ((direct || d2) ? base : rtb) : (gl ? rtb : kInf), nl, 64), t_ef = __shfl(efirst, nl, 64);
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
                         tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
                         const uint32_t t0 = q * kSkipEvery;
@@ -665,7 +675,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                                 }
                             }
                             if (on[u] && taddr[u] != kInf) pool[taddr[u] + i + ioff[u]] = rn;
-                            csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
+                            if (!MAT) csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
                             r[u] = rn; trel[u] = on[u] ? tn : trel[u];              // (a lane past its task keeps adding to r: nobody reads it)
                         }
                     }
@@ -695,8 +705,8 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                             scr[ib + 2 * jk + 1] = (T)(jn | ((t + joff) << 16)); joff += jn; jk++;
                             if (jk < ic) { jl = (uint32_t)scr[ib + 2 * jk]; jn = (uint32_t)scr[ib + 2 * jk + 1] & 0xFFFFu; } else jl = kInf;
                         }
-                        if (stored) pool[((direct || d2) ? base : rtb) + t + joff] = r;
-                        csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
+                        if (stored || gl) pool[((direct || d2) ? base : rtb) + t + joff] = r;
+                        if (!MAT) csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
                         if (rr > pend) { bad = true; break; }
                     }
                 }
@@ -729,7 +739,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 const bool ch = nl != lvl; lvl = nl;
                 if (!ballot(ch)) break;
             }
-            const bool emits = emitn && stored && !direct && !d2;
+            const bool emits = emitn && (stored || gl) && !direct && !d2;
             const bool fills = act && d2;                                     // their intervals are written by the extras pass of level 0
             if (emits) pool[rtb + nres] = sentinel<T>();                      // guard behind the node's residual positions
             uint64_t remaining = ballot(emits || fills);
@@ -761,6 +771,11 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                         const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                         const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
+                        bool t_gl = false; int64_t* gp = nullptr;             // MAT: the task's list is a leaf merged straight into the output
+                        if (MAT) {
+                            const uint32_t s_gl = (uint32_t)__shfl((int)(gl ? 1 : 0), nl, 64), g_lo = __shfl((uint32_t)gofs, nl, 64), g_hi = __shfl((uint32_t)(gofs >> 32), nl, 64);
+                            t_gl = s_gl != 0; gp = a.succ + (((uint64_t)g_hi << 32) | g_lo);
+                        }
                         T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false, isfill = false;
                         uint32_t f_k0 = 0, f_k1 = 0;
                         if (anyf) {                                           // (wave-uniform: the shuffles are executed by every lane)
@@ -799,9 +814,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                         wave_sync();                                      // the parked values have been read: positions may replace them
                         if (tl && len) {
-                            if (isfill) { for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); fsum += mix_node<T>(f_k0, f_k1, (T)(vv + i), nb_lo, nbz); } }
+                            if (isfill) { for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); if (!MAT) fsum += mix_node<T>(f_k0, f_k1, (T)(vv + i), nb_lo, nbz); } }
                             else if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
-                            else { pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
+                            else { if (MAT && t_gl) gp[pe] = (int64_t)((uint64_t)vv + nbase); else pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
                         }
                         wave_sync();
                     }
@@ -847,6 +862,11 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                     const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
                     const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
+                    bool t_gl = false; int64_t* gp = nullptr;
+                    if (MAT) {
+                        const uint32_t s_gl = (uint32_t)__shfl((int)(gl ? 1 : 0), nl, 64), g_lo = __shfl((uint32_t)gofs, nl, 64), g_hi = __shfl((uint32_t)(gofs >> 32), nl, 64);
+                        t_gl = s_gl != 0; gp = a.succ + (((uint64_t)g_hi << 32) | g_lo);
+                    }
                     uint32_t p = 0, pstop = 0, ri = 0, rnext = kInf, ivk = t_ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = t_bc;
                     T ivleft = 0;
                     if (tl) {
@@ -889,8 +909,11 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const bool ii = io < ivlen;                                       // LongIntervalSequenceIterator.java:71-78
                         const bool emit = todo && !isr;
                         const T vv = ii ? (T)(ivleft + (T)io) : cv;
-                        if (emit) out[p] = vv;
-                        zsum += mix_node<T>(t_k0, emit ? t_k1 : 0u, vv, nb_lo, nbz);
+                        if (MAT) { if (emit) { if (t_gl) gp[p] = (int64_t)((uint64_t)vv + nbase); else out[p] = vv; } }
+                        else {
+                            if (emit) out[p] = vv;
+                            zsum += mix_node<T>(t_k0, emit ? t_k1 : 0u, vv, nb_lo, nbz);
+                        }
                         const bool cp = emit && !ii;                                      // a copied element: MaskedLongIterator.java:81-100
                         qcur += cp ? 1u : 0u; krem -= cp ? 1u : 0u;
                         const bool cross = cp && krem == 0;                               // the keep block ended: skip block bi, enter keep block bi + 1
@@ -916,7 +939,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             const uint32_t tqL = BVG_T0();
             // a leaf's items: its kept copy blocks -- block 2j of the copy mask, and the implicit tail behind an even number of blocks
             // (MaskedLongIterator.java:73-78): runs [start, end) of the referenced list -- and its intervals
-            const bool leaf = emitn && !stored && rep;
+            const bool leaf = !MAT && emitn && !stored && rep;
             const uint32_t nkept = (leaf && ref > 0) ? ((bc + 2u) >> 1) : 0u;
             const uint32_t Ln = leaf ? nkept + ic : 0u;
             const uint32_t lincl = wave_incl_scan32(Ln), lfirst = lincl - Ln, Q = lane_get(lincl, 63);
@@ -982,6 +1005,19 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             }
             BVG_T1(10, tqL);
             if (rep) { blk_arcs += d; blk_nodes += 1; }
+            if (MAT) {
+                // the lists of the sub-row that were built in the pool leave in coalesced runs (one list after the other: a wave-uniform loop)
+                wave_sync();
+                uint64_t cm = ballot(rep && stored && d > 0);
+                while (cm) {
+                    const uint32_t j = (uint32_t)__ffsll((unsigned long long)cm) - 1u; cm &= cm - 1ull;
+                    const uint32_t sb0 = lane_get(base, j), dd = lane_get(d, j);
+                    int64_t* const dst = a.succ + lane_get64(gofs, j);
+                    for (uint32_t t = lane; t < dd; t += 64) dst[t] = (int64_t)((uint64_t)pool[sb0 + t] + nbase);
+                }
+                if (rep && a.outdeg) a.outdeg[x - a.from] = (int32_t)d;
+                if (act && stored && !copied_from) nd_base[(uint32_t)x & RM] = (uint16_t)kNoList;   // nobody copies from it: the next compaction drops it
+            }
             wave_sync();
             sa = se;
             if (sa < K1) compact(r0 + (int64_t)sa);                            // the next sub-row starts from the stored lists of the W nodes before it
@@ -1025,18 +1061,25 @@ size_t scan_static_lds() { return (size_t)kRing * 4; }
 
 template <int OCC, bool D2> static void launch_scan_occ(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
     const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
-    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, OCC, D2>), dim3(nblocks), dim3(64), dyn, s, a); }
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+}
+// the materialising form: no checksum, so the node base only shifts what is written (one instantiation for every base)
+template <bool D2> static void launch_scan_mat(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
+    const bool z3 = a.cod.zeta_k == 3;
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
 
-void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, hipStream_t s) {
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, bool materialise, hipStream_t s) {
     if (nblocks == 0) return;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
     // D2 (lists without reference decoded in place around their intervals): only where such lists exist and are copied from
     const bool d2 = a.min_interval != 0 && a.window > 0 && !(knob("BVG_NO_D2") && atoi(knob("BVG_NO_D2")));
-    if (many_waves) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
+    if (materialise) { if (d2) launch_scan_mat<true>(a, nblocks, wide, dyn, s); else launch_scan_mat<false>(a, nblocks, wide, dyn, s); }
+    else if (many_waves) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
     else if (d2) launch_scan_occ<4, true>(a, nblocks, wide, dyn, s);
     else launch_scan_occ<4, false>(a, nblocks, wide, dyn, s);
 }
