@@ -509,6 +509,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.dbg &= (16u | 32u | 64u);                             // forcing an emission form and the work counters leave the results alone; the
                                                             // phase-skipping bits (1, 2, 4, 128) exist in the profiling build only
 #endif
+    // The COUNTING pass of the index build needs the record headers only (a node's entry count follows from its residual count): the
+    // row kernels skip the residual decode and the emission there (the same switches the profiling build skips phases with), which
+    // turns the first of the two index passes into a header walk.  Pool sizing and every fail-over stay as in the filling pass, so a
+    // block is counted in the tier that will fill it.
+    if (g->skip_mode == 1) a.dbg |= 3u;
     // Row-kernel variant: splitting lists into tasks pays on dense or reference-free graphs; sparse graphs with reference
     // chains (several short levels per row) are served better by the pipelined node-per-lane loop alone.
     {
@@ -518,6 +523,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         a.pass_cost = knob("BVG_PASSCOST") ? (uint32_t)strtoul(knob("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
+    a.xcds = knob("BVG_XCDS") ? (uint32_t)std::max(1, atoi(knob("BVG_XCDS"))) : 8u;
     a.wide_half = knob("BVG_WIDE_HALF") ? strtoull(knob("BVG_WIDE_HALF"), nullptr, 10) : 0x80000000ull;
     if (!batch && rows_default && skx && skx->wide == wide) {
         a.skip_first = skx->d_first; a.skip_bit = skx->d_bit; a.skip_val = skx->d_val; a.skip_fmt = skx->d_fmt;

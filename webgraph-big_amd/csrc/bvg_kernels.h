@@ -94,6 +94,7 @@ struct DecodeArgs {
     uint8_t* skip_fmt;                  // per block: who filled its entries (skip_mode 2) -- 1 = row kernels (one slot per entry), 2 = the giant
                                         // kernel (two slots per entry: 32-bit offsets); a kernel uses only entries of its own format
     uint32_t skip_mode;
+    uint32_t xcds;                      // XCDs the work order is laid out for (8 on MI355X; 1 = plain order): xcd_order(), bvg_rows_common.h
 };
 
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);

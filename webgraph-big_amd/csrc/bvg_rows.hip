@@ -49,7 +49,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                                                   // the compiler may not cache (a `volatile` here compiles to flat sc0 sc1 + vmcnt(0))
 
     const unsigned lane = threadIdx.x;
-    const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
+    const uint32_t wi = xcd_order(blockIdx.x, gridDim.x, a.xcds);                      // neighbouring blocks on one XCD (bvg_rows_common.h)
+    const uint32_t bid = a.work_list ? a.work_list[wi] : (a.blk_lo + wi);
     const int64_t s = (int64_t)a.blk_first[bid], e = (int64_t)a.blk_first[bid + 1];
     if (e <= a.from || s >= a.to || s >= e) return;
     const uint32_t halo = a.blk_halo[bid];

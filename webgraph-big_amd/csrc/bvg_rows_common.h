@@ -14,6 +14,17 @@ constexpr uint32_t kMinTask = 4;               // shortest task (outputs) worth 
 
 template <typename T> __device__ __forceinline__ T sentinel() { return (T)~(T)0; }
 
+// XCD-aware work order.  The hardware deals workgroups to the 8 XCDs of an MI355X round robin (workgroup i runs on XCD i mod 8), and
+// every XCD has an L2 of its own.  Consecutive node blocks share what lies at their seam -- the 128-byte line of the stream the boundary
+// falls into, the halo records the later block decodes again, the lines of the offsets and of the skip entries -- so they should meet in
+// ONE L2: workgroup i takes position (i mod 8) * ceil-share + i / 8 of the work list, i.e. each XCD walks its own contiguous eighth of the
+// list in order (a bijection of [0, G) for every G).  `xcds` = 1 restores the plain order (experiments).
+__device__ __forceinline__ uint32_t xcd_order(uint32_t i, uint32_t G, uint32_t xcds) {
+    if (xcds <= 1 || G < 2 * xcds) return i;
+    const uint32_t x = i % xcds, slot = i / xcds, q = G / xcds, r = G % xcds;
+    return x * q + (x < r ? x : r) + slot;
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan32(uint32_t v) { return wave_incl_scan(v); }
 
 // lower bound in a sorted LDS array: number of elements < v

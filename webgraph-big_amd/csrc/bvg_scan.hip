@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     __shared__ uint16_t nd_d[kRing];              // outdegree, clamped (a list longer than the pool fails the block before anything copies from it)
 
     const unsigned lane = threadIdx.x;
-    const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
+    const uint32_t wi = xcd_order(blockIdx.x, gridDim.x, a.xcds);                      // neighbouring blocks on one XCD (bvg_rows_common.h)
+    const uint32_t bid = a.work_list ? a.work_list[wi] : (a.blk_lo + wi);
     const int64_t s = (int64_t)a.blk_first[bid], e = (int64_t)a.blk_first[bid + 1];
     if (e <= a.from || s >= a.to || s >= e) return;
     const uint32_t halo = a.blk_halo[bid];
@@ -593,7 +594,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         // long tasks [0, NL): segment t - (tasks of the lanes before) of the lane that owns it; short tails [NL, Ttot): the
                         // last segment of the (t - NL)-th lane that has one
                         const bool isl = t < NL;
-                        const uint32_t lown = task_owner(tincl, isl ? t : 0u), sown = select_bit(smask, (tl[u] && !isl) ? t - NL : 0u);
+                        // (both searches are wave-uniformly skipped when this pass holds no task of their kind: the short tails sit in the last pass only)
+                        const bool anylong = p0 + 64u * u < NL, anyshort = p0 + 64u * u + 63u >= NL && NL < Ttot;
+                        const uint32_t lown = anylong ? task_owner(tincl, isl ? t : 0u) : 0u, sown = anyshort ? select_bit(smask, (tl[u] && !isl) ? t - NL : 0u) : 0u;
                         const int nl = tl[u] ? (int)(isl ? lown : sown) : (int)lane;
                         const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64), s_ce = (uint32_t)__shfl((int)ce, nl, 64);
                         const uint32_t q = tl[u] ? (isl ? t - s_ts : s_ce) : 0u;
