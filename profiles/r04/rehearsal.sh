@@ -1,10 +1,10 @@
 #!/bin/bash
 # N ranks on the ONE GPU of the box (gloo for the 16-byte reduction: RCCL wants a device per rank; the pool lets at most 6 processes share
-# the card, so 6 is the largest rehearsal this box can hold): `python bench.py --gpus N` starts its own ranks; rank 0 generates the bases
+# the card, and the launcher counts: 5 ranks is the largest rehearsal this box holds): `python bench.py --gpus N` starts its own ranks; rank 0 generates the bases
 # once and shares them through /dev/shm; every rank builds the skip index of ITS shard only, gates its own shard (tiles against the CPU
 # oracle, the shard against the sum of its pieces) and reports its kernel time; the reduced {arcs, chk} must not depend on N.
 cd "$(dirname "$0")/../.."; mkdir -p gpurun_out; out=gpurun_out/r04_strong_rehearsal.txt; : > $out
-for n in 1 2 4 6; do
+for n in 1 2 4 5; do
   echo "== python bench.py --gpus $n --backend gloo --one-device --target-gib 3 --steps 3 --warmup 1 --no-cpu-baseline" >> $out
   timeout -k 10 500 python bench.py --gpus $n --backend gloo --one-device --target-gib 3 --steps 3 --warmup 1 --no-cpu-baseline 2>> gpurun_out/r04_strong_rehearsal.err | python3 -c "
 import sys, json

@@ -41,6 +41,8 @@ namespace {
 
 constexpr uint32_t kDefaultBlockBits = 32768;   // ~4 KiB of compressed stream per wavefront
 constexpr uint64_t kPad = 64;                   // zero bytes after the stream (8-byte loads + record overruns)
+constexpr uint32_t kGiantResident = 512;        // giant workgroups (1 024 threads) that can be resident at once: 2 per CU
+constexpr uint32_t kGiantSlots = 768;           // their work areas: half as many again (a free one always turns up)
 
 // a device allocation freed on every return path
 struct DevBuf {
@@ -134,7 +136,7 @@ struct bvg_graph {
     // predicted tiers run concurrently with tier 0 on high-priority side streams (their few, long blocks are the critical path)
     static constexpr int kSide = 5;            // [0] giants (global-memory kernel), [1..4] one per LDS size class
     hipStream_t side[kSide] = {}; hipEvent_t side_ev[kSide] = {};
-    void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0;
+    void* giant_ws = nullptr; uint64_t giant_ws_bytes = 0; uint32_t* d_gslots = nullptr;   // work areas of the giant kernel: kGiantSlots slots + their busy flags
     void* flow_ws = nullptr; size_t flow_ws_bytes = 0; uint32_t flow_waves = 0;   // scratch of the flow scan kernel (bvg_flow.hip): one slice per resident wavefront
     void* dr_ws = nullptr; size_t dr_ws_bytes = 0;   // bvg_decode_range / bvg_successors_batch workspace, kept between calls (grown on demand)
     void* tr_ws = nullptr; size_t tr_ws_bytes = 0;   // bvg_transpose workspace, kept between calls
@@ -775,24 +777,33 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 pd.plan_version = pl.version; pd.skip_gen = sgen; pd.lo = lo; pd.n = nblocks; pd.pool0 = pool0; pd.giant_need = gneed;
             }
             // giants: global-memory pools sized to the largest list, allocated before anything is launched
-            uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0;
+            uint64_t gpool_elems = 0, gscr_elems = 0; uint32_t gbatch = 0; bool use_slots = false;
             const uint32_t ngiant = pd.count[5] + pd.count[6];
             if (ngiant) {
                 // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
                 gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(ngiant, knob("BVG_GBATCH") ? (uint32_t)std::max(1, atoi(knob("BVG_GBATCH"))) : 8192u);   // (larger batches bought nothing on the 157 k giants of the 4.4 G-node run: the kernel's rate is per block)
-                {   // every giant block of the scan in one launch where memory allows (batches run one after the other on their side
-                    // stream, and the first one shares the chip with tier 0 for the whole scan: profiles/r03_ktrace_d14.txt), at most 1/8 of what is free
+                // Work areas: as many SLOTS as giant workgroups can be resident at once (2 per CU: 1 024 threads each) and half as many again, whatever the
+                // number of giant blocks -- the kernel takes a free slot when a workgroup starts (DecodeArgs::gslots).  Round 3 sized one area per block of
+                // a batch of 8 192 (up to 1/8 of the free memory: 26-31 GB on the default workload, per handle).  All giants go in ONE launch.
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(kGiantSlots, ngiant);
+                if (knob("BVG_GBATCH")) gbatch = (uint32_t)std::max(1, atoi(knob("BVG_GBATCH")));   // (experiments: batched launches, one area per block of a batch)
+                use_slots = !knob("BVG_GBATCH");
+                {
                     size_t free_b = 0, total_b = 0;
                     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / 8;
-                        gbatch = (uint32_t)std::max<uint64_t>(std::min<uint64_t>(gbatch, room / std::max<uint64_t>(per, 1)), std::min<uint32_t>(ngiant, 256u));
+                        const uint64_t per = (gpool_elems + gscr_elems) * esz, room = ((uint64_t)free_b + g->giant_ws_bytes) / 4;
+                        const uint64_t fit = room / std::max<uint64_t>(per, 1);
+                        if (fit < gbatch) { gbatch = (uint32_t)std::max<uint64_t>(fit, 1); if (gbatch < std::min<uint32_t>(kGiantResident, ngiant)) use_slots = false; }   // too few slots for every resident workgroup: batches again
                     }
                 }
                 const uint64_t bytes = (uint64_t)gbatch * (gpool_elems + gscr_elems) * esz;
                 if (bytes > g->giant_ws_bytes) {
                     if (g->giant_ws) { (void)hipFree(g->giant_ws); g->giant_ws = nullptr; g->giant_ws_bytes = 0; }
                     if (hipMalloc(&g->giant_ws, bytes) == hipSuccess) g->giant_ws_bytes = bytes; else gbatch = 0;   // fall back to the cascade
+                }
+                if (use_slots && gbatch) {
+                    if (!g->d_gslots && hipMalloc(&g->d_gslots, kGiantSlots * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); g->d_gslots = nullptr; use_slots = false; gbatch = std::min<uint32_t>(gbatch, 256u); }
+                    if (use_slots) HIPCHK(hipMemsetAsync(g->d_gslots, 0, kGiantSlots * sizeof(uint32_t), g->stream));   // (ordered before the side streams by ev0 below)
                 }
             }
             HIPCHK(hipEventRecord(g->ev0, g->stream));
@@ -815,18 +826,22 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
             auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
-            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 16, materialise, g->stream); launches++; alone(g->stream); }
+            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), materialise, g->stream); launches++; alone(g->stream); }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
-                for (int c = 5; c <= 6; c++)
-                    for (uint32_t o2 = 0; o2 < pd.count[c]; o2 += gbatch) {
+                for (int c = 5; c <= 6; c++) {
+                    const bool slots = use_slots && c == 5;                       // (the generic kernel keeps one area per block of a batch)
+                    ag.gslots = slots ? g->d_gslots : nullptr; ag.gnslots = slots ? gbatch : 0u;
+                    const uint32_t step = slots ? std::max<uint32_t>(pd.count[c], 1u) : gbatch;
+                    for (uint32_t o2 = 0; o2 < pd.count[c]; o2 += step) {
                         ag.work_list = pd.d_lists + offc[c] + o2;
-                        const uint32_t nb = std::min<uint32_t>(gbatch, pd.count[c] - o2);
+                        const uint32_t nb = std::min<uint32_t>(step, pd.count[c] - o2);
                         if (c == 5) launch_giant_decode(ag, nb, wide, materialise, g->side[0]);
                         else launch_decode(ag, nb, wide, materialise, true, g->side[0]);
                         launches++; alone(g->side[0]);
                     }
+                }
             }
             for (int c = 4; c >= 1; c--) {                                     // LDS size classes, largest first
                 if (!pd.count[c]) continue;
@@ -844,7 +859,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 launch_scan_decode(ac, pd.count[7 + c], wide, false, materialise, side_of(c)); alone(side_of(c));
                 launches++;
             }
-            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 16, materialise, g->stream); launches++; alone(g->stream); }
+            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), materialise, g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
@@ -1469,6 +1484,7 @@ void bvg_close(bvg_graph* g) {
     if (g->d_fail) (void)hipFree(g->d_fail);
     if (g->slow_ws) (void)hipFree(g->slow_ws);
     if (g->giant_ws) (void)hipFree(g->giant_ws);
+    if (g->d_gslots) (void)hipFree(g->d_gslots);
     if (g->pred.d_lists) (void)hipFree(g->pred.d_lists);
     for (int i = 0; i < bvg_graph::kSide; i++) { if (g->side[i]) { (void)hipStreamSynchronize(g->side[i]); (void)hipStreamDestroy(g->side[i]); } if (g->side_ev[i]) (void)hipEventDestroy(g->side_ev[i]); }
     release_shared(g->sh);

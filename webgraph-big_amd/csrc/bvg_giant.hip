@@ -101,8 +101,18 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
     const int64_t hs = s - (int64_t)halo;
     const int64_t rep_lo = s > a.from ? s : a.from, rep_hi = e < a.to ? e : a.to;
 
-    T* const pool = reinterpret_cast<T*>(a.gpool) + (uint64_t)blockIdx.x * a.gpool_elems;
-    uint64_t* const scr = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.gscr) + (uint64_t)blockIdx.x * a.gscr_elems * sizeof(T));
+    // the work area: slot blockIdx.x of a batched launch, or -- one launch for all the giants -- a slot taken from the launch's shared set: there are more
+    // slots than workgroups can be resident at once, so a free one always turns up, and every holder finishes without waiting for anybody
+    __shared__ uint32_t slot_sh;
+    if (tid == 0) {
+        uint32_t sl = blockIdx.x;
+        if (a.gslots) { sl %= a.gnslots; while (atomicCAS(&a.gslots[sl], 0u, 1u) != 0u) sl = sl + 1u < a.gnslots ? sl + 1u : 0u; }
+        slot_sh = sl;
+    }
+    __syncthreads();
+    const uint32_t slot = slot_sh;
+    T* const pool = reinterpret_cast<T*>(a.gpool) + (uint64_t)slot * a.gpool_elems;
+    uint64_t* const scr = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(a.gscr) + (uint64_t)slot * a.gscr_elems * sizeof(T));
     const uint64_t CAP = a.gpool_elems < 0xFFFFFFF0ull ? a.gpool_elems : 0xFFFFFFF0ull;    // (positions inside the area are 32-bit)
     const uint64_t SCR = a.gscr_elems * sizeof(T) / sizeof(uint64_t);
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
@@ -718,10 +728,12 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         __syncthreads();
     }
 
+    __syncthreads();                                            // every thread is done with the work area: hand the slot back
+    if (a.gslots && tid == 0) { __threadfence(); atomicExch(&a.gslots[slot], 0u); }
     if (failed) {
         if (tid == 0) {
-            uint32_t slot = atomicAdd(a.fail_count, 1u);
-            if (slot < a.fail_cap) { a.fail_list[slot] = bid; if (a.fail_need) a.fail_need[slot] = fail_need; }
+            uint32_t fslot = atomicAdd(a.fail_count, 1u);
+            if (fslot < a.fail_cap) { a.fail_list[fslot] = bid; if (a.fail_need) a.fail_need[fslot] = fail_need; }
         }
         return;
     }

@@ -77,6 +77,9 @@ struct DecodeArgs {
     uint32_t* fail_need;                // per failed block: list-pool elements it would need (0xFFFFFFFF = unknown / other cause)
     // slow-path pools (global memory), per workgroup
     void* gpool; uint64_t gpool_elems; void* gscr; uint64_t gscr_elems;
+    // giant kernel: the work areas are SLOTS shared by the whole launch (as many as workgroups can be resident, not one per block): a workgroup takes a free
+    // one when it starts (atomicCAS on gslots[i]) and hands it back when it ends; nullptr = area blockIdx.x (batched launches)
+    uint32_t* gslots; uint32_t gnslots;
     // fast path: LDS pool / scratch sizes in elements (dynamic shared memory)
     uint32_t lds_pool_elems, lds_scr_elems;
     uint32_t lds_stage_words;           // row-static kernel: LDS window over the stream, in dwords (multiple of 4)

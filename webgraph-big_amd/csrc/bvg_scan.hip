@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         // whoever passes an interval records where it starts; the intervals themselves are filled in by the extras pass of level 0.
         // (not in the 85-VGPR instantiation: its state would spill, and sparse graphs hold few intervals; on1: `stored` is set for lanes
         // behind the super-row too when the peek is unknown)
-        const bool d2 = D2 && OCC == 4 && on1 && stored && ref == 0 && ic != 0;
+        const bool d2 = D2 && OCC <= 5 && on1 && stored && ref == 0 && ic != 0;
         if (ballot(d2)) {                                                      // default start of interval k: behind every residual and the intervals before it
             if (d2) {
                 uint32_t pre = nres;
@@ -586,7 +586,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     const uint32_t tq9p = BVG_T0();
                     bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
                     uint32_t ivl[RU], ivn[RU], ivk[RU], ioff[RU], tic2[RU], tib2[RU], t0a[RU];   // lists decoded in place around their intervals (d2)
-                    const bool anyd2 = D2 && OCC == 4 && ballot(d2 && act) != 0;
+                    const bool anyd2 = D2 && OCC <= 5 && ballot(d2 && act) != 0;
 #pragma unroll
                     for (uint32_t u = 0; u < RU; u++) {
                         const uint32_t t = p0 + 64u * u + lane;
@@ -1082,6 +1082,7 @@ void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     // D2 (lists without reference decoded in place around their intervals): only where such lists exist and are copied from
     const bool d2 = a.min_interval != 0 && a.window > 0 && !(knob("BVG_NO_D2") && atoi(knob("BVG_NO_D2")));
     if (materialise) { if (d2) launch_scan_mat<true>(a, nblocks, wide, dyn, s); else launch_scan_mat<false>(a, nblocks, wide, dyn, s); }
+    else if (knob("BVG_SCAN_OCC") && atoi(knob("BVG_SCAN_OCC")) == 5) { if (d2) launch_scan_occ<5, true>(a, nblocks, wide, dyn, s); else launch_scan_occ<5, false>(a, nblocks, wide, dyn, s); }   // experiments: 96 VGPRs, 20 wavefronts per CU
     else if (many_waves) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
     else if (d2) launch_scan_occ<4, true>(a, nblocks, wide, dyn, s);
     else launch_scan_occ<4, false>(a, nblocks, wide, dyn, s);
