@@ -256,6 +256,7 @@ int build_plan(bvg_graph* g, uint32_t block_bits, std::shared_ptr<Plan>& out) {
         auto it = sh->plans.find(block_bits);
         if (it != sh->plans.end()) { out = it->second; return 0; }
     }
+    struct WallClock { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~WallClock() { if (dbg_on()) fprintf(stderr, "[bvg] block plan built in %.3f s (wall clock)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } } wall_clock;
     std::shared_ptr<Plan> np = std::make_shared<Plan>();
     Plan& plan = *np;
     plan.device = sh->device;
@@ -426,10 +427,13 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
         return 0;
     };
     DevBuf cnt_d;
+    const auto tb0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count(); };
     if (cnt_d.alloc((size_t)nblk * sizeof(uint32_t)) || hipMemset(cnt_d.p, 0, (size_t)nblk * sizeof(uint32_t)) != hipSuccess) return give_up();
     g->skip_mode = 1; g->skip_cnt = (uint32_t*)cnt_d.p;
     int r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_cnt = nullptr;
+    const double t_count = since();
     std::vector<uint32_t> cnt(nblk);
     if (!r && hipMemcpy(cnt.data(), cnt_d.p, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
     if (r) return give_up();                                                      // a bad stream surfaces in the caller's own decode
@@ -441,6 +445,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
         hipMalloc(&ix->d_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16) != hipSuccess) return give_up();
     if (hipMemcpy(ix->d_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return give_up();
     ix->total = total;
+    const double t_alloc = since();
     g->skip_mode = 2; g->skip_building = ix;
     r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_building.reset();
@@ -448,7 +453,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     ix->h_fmt.resize(nblk);
     if (hipMemcpy(ix->h_fmt.data(), ix->d_fmt, nblk, hipMemcpyDeviceToHost) != hipSuccess) return give_up();
     ix->h_first.swap(first);
-    if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0);
+    if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB; wall clock: counting pass %.3f s, prefix + allocation %.3f s, filling + validating pass %.3f s\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0, t_count, t_alloc - t_count, since() - t_alloc);
     return publish();
 }
 
@@ -853,7 +858,12 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             for (int c = 4; c >= 1; c--) {                                     // the same classes of the lean scan kernel
                 if (!pd.count[7 + c]) continue;
                 DecodeArgs ac = af; ac.work_list = pd.d_lists + offc[7 + c];
-                ac.lds_pool_elems = lclasses[c - 1]; ac.lds_scr_elems = std::max<uint32_t>(1024, lclasses[c - 1] / 4); ac.lds_stage_words = 1024;
+                // LDS geometry of the lean classes (round 4): windows of 256 / 384 / 512 / 768 dwords and scratch areas of 384 / 512 / 1 024 / 2 048 elements instead of
+                // 1 024 dwords and >= 1 024 elements throughout -- resident wavefronts per CU 9 -> 14 / 6 -> 8 / 3 -> 4 in the three populated classes; alone on the chip
+                // they take 53.3 instead of 63.3 ms, in the concurrent schedule the scan gains 1.9 % (profiles/r04_serial_classes.txt, r04_ab_prio.txt); the few
+                // blocks whose longest record no longer fits the window fail over to the row kernel's classes (1 821 of 774 k)
+                static const uint32_t cstage[4] = {256, 384, 512, 768}, cscr[4] = {384, 512, 1024, 2048};
+                ac.lds_pool_elems = lclasses[c - 1]; ac.lds_scr_elems = cscr[c - 1]; ac.lds_stage_words = cstage[c - 1];
                 if (knob("BVG_CLASS_STAGE")) { unsigned v[4] = {1024, 1024, 1024, 1024}; sscanf(knob("BVG_CLASS_STAGE"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_stage_words = std::min(2048u, std::max(128u, v[c - 1] & ~3u)); }   // experiments: the classes' LDS geometry
                 if (knob("BVG_CLASS_SCR")) { unsigned v[4] = {1024, 1024, 2048, 3072}; sscanf(knob("BVG_CLASS_SCR"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_scr_elems = std::min(8192u, std::max(128u, v[c - 1])); }
                 launch_scan_decode(ac, pd.count[7 + c], wide, false, materialise, side_of(c)); alone(side_of(c));

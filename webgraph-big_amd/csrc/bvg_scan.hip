@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         BVG_T1(6, tq5);
         const uint32_t tq7 = BVG_T0();
         // ------------------------------------------------------------------ phase 1: every lane parses the header of its record
+#ifdef BVG_EXP_PRIO
+        __builtin_amdgcn_s_setprio(3);                                        // experiment: the lock-step header parse ahead of the other wavefronts' bulk loops
+#endif
         uint32_t ref = 0, bc = 0, ic = 0, nres = 0, sb = 0, ib = 0;
         int32_t extra = (int32_t)d;                                           // (32-bit arithmetic from here on: the lists of this kernel hold 32-bit ids,
         uint32_t big = 0;                                                     //  and a code value that would not fit fails the block)
@@ -421,6 +424,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             nres = (uint32_t)extra;
         }
           // the touches have landed long ago; their registers are free again
+#ifdef BVG_EXP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (ballot(bad && lane < K1)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
         BVG_T1(7, tq7);
         const uint32_t tq8 = BVG_T0();
@@ -630,6 +636,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                     }
                     BVG_T1(14, tq9p);
+#ifdef BVG_EXP_UNROLL
+#pragma unroll 2
+#endif
                     for (uint32_t i = 0;; i++) {
 #ifdef BVG_ABLATE_RESLOOP
                         break;
@@ -1083,6 +1092,7 @@ void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     const bool d2 = a.min_interval != 0 && a.window > 0 && !(knob("BVG_NO_D2") && atoi(knob("BVG_NO_D2")));
     if (materialise) { if (d2) launch_scan_mat<true>(a, nblocks, wide, dyn, s); else launch_scan_mat<false>(a, nblocks, wide, dyn, s); }
     else if (knob("BVG_SCAN_OCC") && atoi(knob("BVG_SCAN_OCC")) == 5) { if (d2) launch_scan_occ<5, true>(a, nblocks, wide, dyn, s); else launch_scan_occ<5, false>(a, nblocks, wide, dyn, s); }   // experiments: 96 VGPRs, 20 wavefronts per CU
+    else if (knob("BVG_SCAN_OCC") && atoi(knob("BVG_SCAN_OCC")) == 50) launch_scan_occ<5, false>(a, nblocks, wide, dyn, s);   // ... without the in-place decode around intervals (14 spills instead of 38)
     else if (many_waves) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
     else if (d2) launch_scan_occ<4, true>(a, nblocks, wide, dyn, s);
     else launch_scan_occ<4, false>(a, nblocks, wide, dyn, s);
