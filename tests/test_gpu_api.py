@@ -256,6 +256,33 @@ def test_device_index_is_saved_and_loaded_back(W, tools, oracle, tmp_path, capfd
     h.close()
 
 
+@pytest.mark.parametrize("shape", ["eu", "heavy_tail", "w0", "gamma_residuals"])
+def test_dense_walk_builds_the_same_index_as_the_one_pass_build(W, tools, oracle, tmp_path, monkeypatch, shape):
+    """Round 4 fills the skip entries by a dense walk (csrc/bvg_index.hip: one lane per long list, every coding) and validates the blocks in a pass
+    that decodes WITH those entries and checks each of them against the stream; round 3 walked, filled and validated in one index-less pass of the
+    row kernel (BVG_INDEX_WALK=0).  Both must leave the same index, byte for byte (entries, marks, plan: the payload of basename.bvgidx), and the same scans."""
+    import os
+    kw, synth, n = {}, tools.eu_like(mean_deg=70.0), 50000
+    if shape == "heavy_tail": synth, n = tools.eu_like(max_deg=30000, tail_alpha=1.6, mean_deg=40.0), 20000
+    if shape == "w0": synth, kw = tools.web_like(mean_deg=40.0), dict(window_size=0, max_ref_count=0, min_interval_length=0)
+    if shape == "gamma_residuals": kw = dict(residual_coding=W.GAMMA, zeta_k=3)
+    st = tools.synth_store(n, seed=23, params=W.default_params(**kw), synth=synth, threads=4)
+    base = str(tmp_path / "g"); st.write(base)
+    o = oracle.Graph.load(base).scan()
+    files = {}
+    for mode in ("0", None):
+        if mode is None: monkeypatch.delenv("BVG_INDEX_WALK", raising=False)
+        else: monkeypatch.setenv("BVG_INDEX_WALK", mode)
+        g = W.BVGraph.load(base)
+        g.build_index()
+        r = g.scan(); r = g.scan()
+        assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"]) and r["index_entries"] > 0, (shape, mode)
+        p = str(tmp_path / ("idx_%s" % mode)); g.save_index(p); g.close()
+        files[mode] = (open(p, "rb").read(), r["lean_blocks"], r["index_entries"])
+    assert files["0"][1:] == files[None][1:], (files["0"][1:], files[None][1:])
+    assert files["0"][0] == files[None][0], "the two builds left different index files"
+
+
 def test_a_damaged_or_foreign_index_file_is_refused(W, tools, oracle, tmp_path):
     """The lean scan kernel trusts the validation marks of basename.bvgidx, so the file is tied to EVERY byte of the stream and guarded
     by a checksum of its own payload (format 2): a .graph rewritten in place with the same size and other bytes in the middle, a

@@ -444,16 +444,33 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
         hipMalloc(&ix->d_fmt, nblk) != hipSuccess || hipMemset(ix->d_fmt, 0, nblk) != hipSuccess ||
         hipMalloc(&ix->d_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16) != hipSuccess) return give_up();
     if (hipMemcpy(ix->d_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return give_up();
+    // (entries nobody fills -- the allotment of a block that ends in the generic kernel -- read as zero: an index, and its file, are reproducible)
+    if (hipMemsetAsync(ix->d_bit, 0, total * sizeof(uint16_t) + 16, g->stream) != hipSuccess || hipMemsetAsync(ix->d_val, 0, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16, g->stream) != hipSuccess) return give_up();
     ix->total = total;
     const double t_alloc = since();
-    g->skip_mode = 2; g->skip_building = ix;
+    // Filling: a DENSE WALK writes the entries (bvg_index.hip: one lane per long list, the lists of a block queued together), then the validating pass decodes every block
+    // WITH them (skip_mode 3: residual tasks instead of one lane's serial walk per list) and checks each entry against the stream as it goes.  BVG_INDEX_WALK=0: round 3's
+    // single pass (the row kernel walks, fills and validates in one go, index-less).
+    const bool dense_walk = !(knob("BVG_INDEX_WALK") && atoi(knob("BVG_INDEX_WALK")) == 0);
+    double t_walk = t_alloc;
+    if (dense_walk) {
+        DecodeArgs wa{};
+        wa.graph = sh->d_graph; wa.limit_byte = sh->nbytes; wa.padded_bytes = sh->padded; wa.offsets = sh->offs; wa.n = sh->p.nodes; wa.from = nfrom; wa.to = nto;
+        wa.blk_first = pl.d_first; wa.blk_halo = pl.d_halo; wa.blk_mask = pl.d_mask; wa.work_list = nullptr; wa.blk_lo = blo;
+        wa.window = sh->p.window_size; wa.min_interval = sh->p.min_interval_length; wa.cod = codings_of(sh->p);
+        wa.skip_first = ix->d_first; wa.skip_bit = ix->d_bit; wa.skip_val = ix->d_val;
+        launch_index_walk(wa, bhi - blo, build_wide, g->stream);
+        if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up();
+        t_walk = since();
+    }
+    g->skip_mode = dense_walk ? 3 : 2; g->skip_building = ix;
     r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_building.reset();
     if (r) return give_up();
     ix->h_fmt.resize(nblk);
     if (hipMemcpy(ix->h_fmt.data(), ix->d_fmt, nblk, hipMemcpyDeviceToHost) != hipSuccess) return give_up();
     ix->h_first.swap(first);
-    if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB; wall clock: counting pass %.3f s, prefix + allocation %.3f s, filling + validating pass %.3f s\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0, t_count, t_alloc - t_count, since() - t_alloc);
+    if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB; wall clock: counting pass %.3f s, prefix + allocation %.3f s, dense walk %.3f s, %s pass %.3f s\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0, t_count, t_alloc - t_count, t_walk - t_alloc, dense_walk ? "validating" : "filling + validating", since() - t_walk);
     return publish();
 }
 
@@ -491,7 +508,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (r) return r;
         }
     }
-    std::shared_ptr<SkipIndex> skx0 = g->skip_mode == 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));
+    std::shared_ptr<SkipIndex> skx0 = g->skip_mode >= 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));
     if (skx0 && g->skip_mode == 0 && (skx0->failed || g->tun.no_index)) skx0.reset();                // a failed build left no arrays; bvg_tuning.no_index: this handle scans without it
     const std::shared_ptr<SkipIndex> skx = skx0;                                                       // held for the whole call
 
@@ -834,6 +851,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), materialise, g->stream); launches++; alone(g->stream); }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
+                if (ag.skip_mode == 3) ag.skip_mode = 2;                              // (the giant kernel fills its own entries, in its own format, while it validates)
                 ag.gscr = (char*)g->giant_ws + (size_t)gbatch * gpool_elems * esz; ag.gscr_elems = gscr_elems; ag.lds_stage_words = 1024;
                 for (int c = 5; c <= 6; c++) {
                     const bool slots = use_slots && c == 5;                       // (the generic kernel keeps one area per block of a batch)
@@ -965,7 +983,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 for (size_t off = 0; off < nwork; off += batch) {
                     uint32_t nb = (uint32_t)std::min<size_t>(batch, nwork - off);
                     a.work_list = d_work + off;
-                    if (giant) launch_giant_decode(a, nb, wide, materialise, g->stream); else launch_decode(a, nb, wide, materialise, true, g->stream);
+                    if (giant) { DecodeArgs ag2 = a; if (ag2.skip_mode == 3) ag2.skip_mode = 2; launch_giant_decode(ag2, nb, wide, materialise, g->stream); } else launch_decode(a, nb, wide, materialise, true, g->stream);
                     launches++;
                 }
             });

@@ -90,7 +90,8 @@ struct DecodeArgs {
     uint32_t dbg;                       // timing experiments only (BVG_DBG): 1 skip emission, 2 skip residual decode, 4 skip parse, 16 force task rows, 32 force pipelined rows, 64 work counters, 128 skip the task merge loop
     // residual skip index (row kernel): for every node with >= kSkipMin residuals, one entry per kSkipEvery residuals
     // {bit offset of that residual's code from the record start, value of the residual before it}; entries of a block
-    // are contiguous, in node order.  skip_mode 1 = count entries per block, 2 = fill them, 0 = use them when present.
+    // are contiguous, in node order.  skip_mode 1 = count entries per block, 2 = fill them (and validate the block), 3 = validate the block decoding
+    // WITH the entries a dense walk has just filled, checking every one (the row kernels; the giant kernel fills its own in this pass), 0 = use them when present.
     const uint64_t* skip_first;         // nblk+1 entry indices, or nullptr
     uint16_t* skip_bit; void* skip_val; // entries: 16-bit bit offset (a record that uses the index fits the LDS window, <= 64 Kbit) + one successor-typed value (4 or 8 bytes)
     uint32_t* skip_cnt;                 // skip_mode 1: per-block entry count out
@@ -137,6 +138,8 @@ inline void launch_flow_scan(const DecodeArgs&, uint32_t, uint32_t, void*, uint3
 void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 
 // sums the result stripes into stripe 0 (one workgroup)
+// the filling pass of the skip index as a dense walk (bvg_index.hip): entries of the blocks of the work list, where the counting pass allotted them
+void launch_index_walk(const DecodeArgs& a, uint32_t nblocks, bool wide, hipStream_t s);
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);
 // *out += position-keyed 64-bit hash of the nbytes at p (device memory, 8-byte aligned); *out must be zeroed by the caller
 void launch_hash_words(const void* p, uint64_t nbytes, unsigned long long* out, hipStream_t s);

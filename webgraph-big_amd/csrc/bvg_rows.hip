@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             sk_run += lane_get(eincl, 63);
         }
         const uint32_t rdst = TASK ? rtb : base + size - nres;
-        if (a.skip_mode == 0 && sk_n != 0 && ballot(cntE != 0) && !(a.dbg & 2)) {
+        if ((a.skip_mode == 0 || a.skip_mode == 3) && sk_n != 0 && ballot(cntE != 0) && !(a.dbg & 2)) {   // (3: the validating pass of the index build decodes WITH the entries the dense walk has just written, and checks every one of them)
             // long residual lists are cut at their skip entries: every segment of <= kSkipEvery gaps is one task
             if (sk_run > sk_n) { failed = true; fail_need = 0xFFFFFFF5u; break; }      // index out of step with the stream
             // long tasks first (full segments and tails of more than kShortTask gaps), the short tails after them: a pass of 64
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (shortt && ss >= p0 && ss < p0 + RP) rtmap[ss - p0] = lane | (cntE << 8);
                 }
                 wave_sync();
-                bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tlast[RU]; T r[RU];
+                bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tlast[RU], tchk[RU], trec[RU]; T r[RU];
 #pragma unroll
                 for (uint32_t u = 0; u < RU; u++) {
                     tl[u] = p0 + 64u * u + lane < Ttot;
@@ -393,6 +393,9 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
                     tlast[u] = (tl[u] && t0 + cnt[u] == t_nres) ? 1u : 0u;
                     taddr[u] = t_dst + t0;
+                    // skip_mode 3: a segment that is not its list's last must END exactly where the next entry says the next one starts, on the value it holds:
+                    // segment 0 starts where the header parse ended, so by induction every entry of a block that passes is the true walk's (bvg_index.hip)
+                    trec[u] = t_rec; tchk[u] = (a.skip_mode == 3 && tl[u] && q < t_ce) ? t_ef + q + 1u : 0u;
                     if (tl[u] && q) {
                         const uint64_t e = sk_base + t_ef + q - 1u;
                         trel[u] = t_rec + a.skip_bit[e]; r[u] = reinterpret_cast<const T*>(a.skip_val)[e];
@@ -442,6 +445,12 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
 #pragma unroll
                 for (uint32_t u = 0; u < RU; u++)
                     if (tlast[u] && cnt[u] && trel[u] != tpend[u] && !tbad && !(a.dbg & 7u)) err |= ERR_MALFORMED;
+#pragma unroll
+                for (uint32_t u = 0; u < RU; u++)
+                    if (tchk[u] && cnt[u]) {
+                        const uint64_t en = sk_base + tchk[u] - 1u;
+                        if (trel[u] != trec[u] + a.skip_bit[en] || r[u] != reinterpret_cast<const T*>(a.skip_val)[en]) tbad = true;
+                    }
                 wave_sync();
             }
             };
@@ -524,7 +533,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             {
                 const uint32_t maxd = wave_max32(emitn ? d : 0u), nlev = wave_max32(emitn ? lvl + 1u : 0u);
                 const uint32_t est = ((rowW * 21u) >> 10) + nlev * a.pass_cost;
-                by_tasks = (est < maxd || (a.dbg & 16u) || a.skip_mode == 2) && !(a.dbg & 32u);   // (the index-filling pass is the validating pass: bvg_scan.hip)
+                by_tasks = (est < maxd || (a.dbg & 16u) || a.skip_mode >= 2) && !(a.dbg & 32u);   // (the index-filling pass is the validating pass: bvg_scan.hip)
             }
             bool zbad = malf;
             if (by_tasks && act && bc) {                                      // copy blocks -> prefix form (MaskPrefix), once per row
@@ -867,7 +876,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     blk_arcs = wave_sum64(blk_arcs); blk_chk = wave_sum64(blk_chk); blk_nodes = wave_sum64(blk_nodes);
     if (lane == 0) {
         if (a.skip_mode == 1 && a.skip_cnt) a.skip_cnt[bid] = sk_run;
-        if (a.skip_mode == 2 && a.skip_fmt && sk_have) a.skip_fmt[bid] = (TASK && validated && err == 0) ? 1 : 3;   // 1: the lean scan kernel may take the block
+        if (a.skip_mode >= 2 && a.skip_fmt && sk_have) a.skip_fmt[bid] = (TASK && validated && err == 0) ? 1 : 3;   // 1: the lean scan kernel may take the block
         unsigned long long* const accs = a.acc + (size_t)(bid & a.acc_mask) * kAccStride;   // this block's result stripe
         atomicAdd(&accs[0], (unsigned long long)blk_arcs);
         atomicAdd(&accs[1], (unsigned long long)blk_chk);
