@@ -131,6 +131,10 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
     const bool sk_use = a.skip_mode == 0 && sk_slots != 0 && a.skip_fmt && a.skip_fmt[bid] == 2;
     const bool sk_fill = a.skip_mode == 2 && sk_any;
     uint32_t sk_run = 0;                                       // slots of the nodes walked so far
+    if (sk_fill && a.skip_val) {                               // the value slots this format leaves unused read as zero, whatever was there (the dense walk of bvg_index.hip visits every block)
+        for (uint32_t i = tid; i < sk_slots; i += GNT) reinterpret_cast<T*>(a.skip_val)[sk_base + i] = (T)0;
+        __syncthreads();
+    }
     auto rd32 = [&](uint64_t sl) -> uint32_t { return (uint32_t)a.skip_bit[sl] | ((uint32_t)a.skip_bit[sl + 1] << 16); };
     auto wr32 = [&](uint64_t sl, uint32_t val) { a.skip_bit[sl] = (uint16_t)(val & 0xFFFFu); a.skip_bit[sl + 1] = (uint16_t)(val >> 16); };
 

@@ -145,7 +145,20 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
     if (qn) walk();
 }
 
+// Entries of blocks that no kernel finished with a mark (fmt 0: they ended in the generic kernel, which uses none) are never read; the dense walk may have
+// written some before the block failed over.  They are cleared, so that an index -- and its file -- does not depend on how it was built.
+__global__ void __launch_bounds__(256) clear_unmarked_entries_kernel(const uint64_t* first, const uint8_t* fmt, uint16_t* bit, void* val, uint32_t blo, uint32_t bhi, int wide) {
+    const uint32_t b = blo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= bhi || fmt[b] != 0) return;
+    for (uint64_t i = first[b]; i < first[b + 1]; i++) { bit[i] = 0; if (wide) reinterpret_cast<uint64_t*>(val)[i] = 0; else reinterpret_cast<uint32_t*>(val)[i] = 0; }
+}
+
 }  // namespace
+
+void launch_clear_unmarked_entries(const uint64_t* first, const uint8_t* fmt, uint16_t* bit, void* val, uint32_t blo, uint32_t bhi, bool wide, hipStream_t s) {
+    if (bhi <= blo) return;
+    hipLaunchKernelGGL(clear_unmarked_entries_kernel, dim3((bhi - blo + 255) / 256), dim3(256), 0, s, first, fmt, bit, val, blo, bhi, wide ? 1 : 0);
+}
 
 // fills the entries of the blocks of the work list (or of blk_lo + [0, nblocks)); `wide`: 64-bit entry values
 void launch_index_walk(const DecodeArgs& a, uint32_t nblocks, bool wide, hipStream_t s) {

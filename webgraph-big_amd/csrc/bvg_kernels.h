@@ -140,6 +140,7 @@ void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool 
 // sums the result stripes into stripe 0 (one workgroup)
 // the filling pass of the skip index as a dense walk (bvg_index.hip): entries of the blocks of the work list, where the counting pass allotted them
 void launch_index_walk(const DecodeArgs& a, uint32_t nblocks, bool wide, hipStream_t s);
+void launch_clear_unmarked_entries(const uint64_t* first, const uint8_t* fmt, uint16_t* bit, void* val, uint32_t blo, uint32_t bhi, bool wide, hipStream_t s);
 void launch_reduce_acc(unsigned long long* acc, uint32_t stripes, hipStream_t s);
 // *out += position-keyed 64-bit hash of the nbytes at p (device memory, 8-byte aligned); *out must be zeroed by the caller
 void launch_hash_words(const void* p, uint64_t nbytes, unsigned long long* out, hipStream_t s);
