@@ -837,6 +837,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             off += pd.count[0];
             size_t offc[12]; { size_t o = 0; for (int c = 0; c < 12; c++) { offc[c] = o; o += pd.count[c]; } }
             const bool tier0_first = knob("BVG_ORDER") && atoi(knob("BVG_ORDER")) == 1;
+            bool t0_waits = false;
             // side streams: [0] the giants and, behind them, the smallest class (short); [1..3] one per larger LDS class, so that every
             // class starts with the main launch and overlaps it.  (One stream per class and one for the giants made six streams: the
             // largest class then started only when the last giant batch had finished -- streams share hardware queues -- and ended 11 ms
@@ -867,6 +868,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                         launches++; alone(g->side[0]);
                     }
                 }
+                // (experiment, BVG_T0WAIT=1: tier 0 starts when the giants are done.  With all giants in one launch they trickle through the whole scan beside tier 0 -- a giant
+                // workgroup needs 16 wave slots of ONE CU at once -- and end ~30 ms after it, profiles/r04_eu15_scan_timeline.txt; holding tier 0 back by the giants' ~30 ms
+                // ends the scan on tier 0 instead and takes exactly as long: 366.0 vs 366.5 ms, profiles/r04_ab_t0wait.txt.  The launches are work-conserving.)
+                if (knob("BVG_T0WAIT") && atoi(knob("BVG_T0WAIT")) == 1 && !tier0_first) { HIPCHK(hipEventRecord(g->side_ev[0], g->side[0])); t0_waits = true; }
             }
             for (int c = 4; c >= 1; c--) {                                     // LDS size classes, largest first
                 if (!pd.count[c]) continue;
@@ -889,6 +894,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 launch_scan_decode(ac, pd.count[7 + c], wide, false, materialise, side_of(c)); alone(side_of(c));
                 launches++;
             }
+            if (t0_waits) HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[0], 0));
             if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), materialise, g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }

@@ -695,7 +695,10 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     for (uint32_t u = 0; u < RU; u++) tbad |= trel[u] > tpend[u];    // ran past the record: checked once, behind the loop (reads past it are harmless)
                 }
                 };
-                if (Ttot > 96u) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
+#ifndef BVG_SCAN_RU2_FROM
+#define BVG_SCAN_RU2_FROM 96
+#endif
+                if (Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
                 bad |= tbad;
             } else if (rparse) {
                 if (nres > 0) {
