@@ -397,14 +397,16 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
 // The fill pass is also the VALIDATING pass: a block it decodes from end to end with the position logic (which refuses streams
 // that overlap, counts that contradict each other, ...) is marked fmt = 1, and only such blocks are given to the lean scan kernel.
 // The result replaces the plan's snapshot; scans that hold the old one keep it alive until they return.
-int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uint32_t bhi, bool retry_failed = false) {
+// `first_scan` (with its node range): the scan whose first call builds the index wants {nodes, arcs, chk} of that very range -- the validating pass decodes every
+// block of the range anyway, so it reports them, and the caller does not scan a second time (only when the index is built for exactly the scan's blocks).
+int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uint32_t bhi, bool retry_failed = false, bvg_scan_result* first_scan = nullptr, int64_t sfrom = 0, int64_t sto = 0, bool* first_scan_done = nullptr) {
     Shared* sh = g->sh;
     std::lock_guard<std::mutex> lk(sh->skip_mu);
     Plan& pl = *plp;
     {
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&pl.skip);
         if (cur && !(cur->failed && retry_failed) && cur->blk_lo <= blo && bhi <= cur->blk_hi) return 0;   // another thread built it meanwhile (or failed to: not tried again here)
-        if (cur && !cur->failed) { blo = 0; bhi = pl.nblk; }                      // a second range: index the whole graph once and for all
+        if (cur && !cur->failed) { blo = 0; bhi = pl.nblk; first_scan = nullptr; }   // a second range: index the whole graph once and for all (the scan's own range is a part of it: it scans afterwards)
     }
     const uint32_t nblk = pl.nblk;
     if (!nblk || sh->p.nodes == 0 || blo >= bhi) return 0;
@@ -464,8 +466,11 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
         t_walk = since();
     }
     g->skip_mode = dense_walk ? 3 : 2; g->skip_building = ix;
-    r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
+    const bool report = first_scan != nullptr && !(knob("BVG_FIRST_SCAN_TWICE") && atoi(knob("BVG_FIRST_SCAN_TWICE")));
+    r = report ? run_decode(g, sfrom, sto, false, nullptr, nullptr, nullptr, first_scan, nullptr, &plp)       // (the same blocks; only what is REPORTED is clipped to the scan's nodes)
+               : run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_building.reset();
+    if (!r && report && first_scan_done) *first_scan_done = true;
     if (r) return give_up();
     launch_clear_unmarked_entries(ix->d_first, ix->d_fmt, ix->d_bit, ix->d_val, blo, bhi, build_wide, g->stream);
     if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up();
@@ -506,8 +511,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&plp->skip);
         const bool covered = cur && cur->blk_lo <= lo && lo + nblocks <= cur->blk_hi;
         if (!covered && (!materialise || (to - from) >= sh->p.nodes / 4)) {
-            r = materialise ? build_skip(g, plp, 0, pl.nblk) : build_skip(g, plp, lo, lo + nblocks);
+            bool scanned = false;
+            r = materialise ? build_skip(g, plp, 0, pl.nblk) : build_skip(g, plp, lo, lo + nblocks, false, res, from, to, &scanned);
             if (r) return r;
+            if (scanned) return 0;                              // the validating pass of the build WAS this scan (same nodes, the checking kernels: bit-exact by construction)
         }
     }
     std::shared_ptr<SkipIndex> skx0 = g->skip_mode >= 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));
