@@ -470,7 +470,12 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     r = report ? run_decode(g, sfrom, sto, false, nullptr, nullptr, nullptr, first_scan, nullptr, &plp)       // (the same blocks; only what is REPORTED is clipped to the scan's nodes)
                : run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_building.reset();
-    if (!r && report && first_scan_done) *first_scan_done = true;
+    if (!r && report) {
+        // the pass decoded with the entries it was validating: the result says so (run_decode could not know their number yet)
+        first_scan->index_entries = total;
+        first_scan->index_bytes += total * (2 + (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) + (uint64_t)(bhi - blo) * 9;
+        if (first_scan_done) *first_scan_done = true;
+    }
     if (r) return give_up();
     launch_clear_unmarked_entries(ix->d_first, ix->d_fmt, ix->d_bit, ix->d_val, blo, bhi, build_wide, g->stream);
     if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up();
