@@ -342,7 +342,10 @@ def main():
                 out["roofline_valu"] = {"bound": "valu-issue", "achieved": ach, "peak": VALU_PEAK_WINSTR_PER_S, "unit": "wave-instr/s", "frac": ach / VALU_PEAK_WINSTR_PER_S,
                                         "valu_per_arc": t["valu_per_arc"], "salu_per_arc": t.get("salu_per_arc"), "lds_per_arc": t.get("lds_per_arc"), "active_lanes": t.get("active_lanes"),
                                         "floor_valu_per_arc": VALU_FLOOR_PER_ARC, "x_floor": t["valu_per_arc"] / VALU_FLOOR_PER_ARC,
-                                        "edges_per_s_at_floor": VALU_PEAK_WINSTR_PER_S / VALU_FLOOR_PER_ARC, "source": t.get("valu_source")}
+                                        "edges_per_s_at_floor": VALU_PEAK_WINSTR_PER_S / VALU_FLOOR_PER_ARC, "source": t.get("valu_source"),
+                                        "peak_full_rate_ops": 1024 / 1.07e-9,
+                                        "note": "peak = 1 024 SIMDs / 1.83 ns, the issue time of the half-rate instructions (shifts left, three-operand integer forms, multiplies, compares, selects: "
+                                                "most of this kernel); v_add/sub/and/or/xor/lshr/mov issue in 1.07 ns (profiles/r04_valu_rates2.txt), so a mix rich in those can pass frac 1"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sts, bases, args.basename, effective_cpus(threads), args.cpu_gib)   # one thread per CPU the box really grants
         print(json.dumps(out))
