@@ -346,7 +346,7 @@ def main():
                                         "peak_full_rate_ops": 1024 / 1.07e-9,
                                         "note": "peak = 1 024 SIMDs / 1.83 ns, the issue time of the half-rate instructions (shifts left, three-operand integer forms, multiplies, compares, selects: "
                                                 "most of this kernel); v_add/sub/and/or/xor/lshr/mov issue in 1.07 ns (profiles/r04_valu_rates2.txt), so a mix rich in those can pass frac 1"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:                      # (rank 0 at N = 1 only: at N > 1 the other ranks would wait for it)
             out["cpu_baseline"] = cpu_baseline(sts, bases, args.basename, effective_cpus(threads), args.cpu_gib)   # one thread per CPU the box really grants
         print(json.dumps(out))
     if dist is not None:

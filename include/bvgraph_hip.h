@@ -144,9 +144,10 @@ void bvg_host_free(void* p);
  * decoded together with the few earlier nodes its reference chain reaches (the recursion of BVG:1084). */
 int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int32_t* outdeg, int64_t* succ, uint64_t succ_cap, uint64_t* n_succ);
 /* Full sequential successor scan of [from,to) consumed on-chip (arc count + checksum).
- * The first scan of >= 4096 nodes also builds the residual skip index of the node blocks it covers (two extra passes; a shard
- * of a multi-GPU scan therefore indexes its own part only, a later scan of other nodes indexes the whole graph); a materialising
- * call (bvg_decode_range) builds it for the whole graph once it covers >= 1/4 of the nodes.  The index is shared by bvg_copy()
+ * The first scan of >= 4096 nodes also builds the residual skip index of the node blocks it covers (a header walk that counts the
+ * entries, a dense walk that fills them, and a validating decode that uses and checks them -- and reports this very scan's result, so
+ * the first scan IS the build; a shard of a multi-GPU scan therefore indexes its own part only, a later scan of other nodes indexes the
+ * whole graph); a materialising call (bvg_decode_range) builds it for the whole graph once it covers >= 1/4 of the nodes.  The index is shared by bvg_copy()
  * flyweights: 6 bytes (10 for graphs on the 64-bit successor kernels: more than 2^32 - 256 nodes) per 16 residuals of lists
  * with >= 24 residuals (cf. the offset cache the reference builds at load, BVG:1545-1558).  The same passes VALIDATE the
  * blocks: the lean scan kernel then skips the checks a well-formed stream cannot fail, blocks that failed one stay on the
