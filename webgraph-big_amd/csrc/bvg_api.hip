@@ -844,9 +844,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             }
             HIPCHK(hipEventRecord(g->ev0, g->stream));
             for (int i = 0; i < bvg_graph::kSide; i++) HIPCHK(hipStreamWaitEvent(g->side[i], g->ev0, 0));
-            size_t off = 0;
             DecodeArgs a0 = a; a0.work_list = pd.d_lists;                      // tier 0 on the main stream
-            off += pd.count[0];
             size_t offc[12]; { size_t o = 0; for (int c = 0; c < 12; c++) { offc[c] = o; o += pd.count[c]; } }
             const bool tier0_first = knob("BVG_ORDER") && atoi(knob("BVG_ORDER")) == 1;
             bool t0_waits = false;

@@ -73,7 +73,6 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
     const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
     const bool nbz = a.node_base == 0;
     const uint32_t stage_bits = kFlowAux * 32u;
-    constexpr uint32_t HM = 0xFFFFu;
 
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
         const uint32_t bid = a.work_list ? a.work_list[wi] : (a.blk_lo + wi);
