@@ -698,7 +698,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 #ifndef BVG_SCAN_RU2_FROM
 #define BVG_SCAN_RU2_FROM 96
 #endif
-                if (Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
+                // Two chains per lane only in the 128-VGPR instantiation: on the final structure the two-chain form measures flat there (thresholds 64 ... never: profiles/r04_ab_t0wait.txt),
+                // and its registers are what the 85-VGPR instantiation of the sparse graphs spills (44 -> 31 spilled VGPRs without it: cnr-2000 +3.4 %, web +2.4 %, profiles/r04_ab_noru2*.txt)
+                if (OCC == 4 && Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
                 bad |= tbad;
             } else if (rparse) {
                 if (nres > 0) {
