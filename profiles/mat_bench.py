@@ -26,3 +26,5 @@ print(shape, 'materialise %d arcs in %.1f ms -> %.1f G edges/s, %.1f GB/s writte
 deg, succ = base.decode_range(0, 1000)
 assert torch.equal(d_succ[:len(succ)].cpu(), torch.from_numpy(succ)) and torch.equal(d_deg[:1000].cpu(), torch.from_numpy(deg))
 print('spot check ok')
+import json, os
+print('JSON ' + json.dumps({'shape': shape, 'arcs': int(arcs), 'nodes': int(n), 'seconds': dt, 'edges_per_s': arcs / dt, 'bytes_written_per_s': arcs * 8 / dt, 'scan_kernel': os.environ.get('BVG_SCANK', '1') != '0', 'all_calls_s': times}))

@@ -38,4 +38,8 @@ rm -rf gpurun_out/r04_kt
 # materialise (bvg_decode_range_dev into HBM): the lean kernel vs the row kernel (BVG_SCANK=0)
 export BVG_TEST_KNOBS=1
 : > gpurun_out/r04_mat_bench.txt
-for cfg in "BVG_SCANK=0" "BVG_NOP=1"; do for shape in eu web; do echo "[$cfg $shape] $(env $cfg timeout -k 10 300 python profiles/mat_bench.py $shape 2>&1 | grep materialise)" | tee -a gpurun_out/r04_mat_bench.txt; done; done
+: > gpurun_out/r04_mat_bench.jsonl
+for cfg in "BVG_SCANK=0" "BVG_NOP=1"; do for shape in eu web; do env $cfg timeout -k 10 300 python profiles/mat_bench.py $shape > gpurun_out/r04_mat_one.log 2>&1; echo "[$cfg $shape] $(grep materialise gpurun_out/r04_mat_one.log)" | tee -a gpurun_out/r04_mat_bench.txt; grep '^JSON ' gpurun_out/r04_mat_one.log | sed 's/^JSON //' >> gpurun_out/r04_mat_bench.jsonl; done; done
+python3 -c "
+import json; rows=[json.loads(l) for l in open('gpurun_out/r04_mat_bench.jsonl')]
+json.dump({'what': 'bvg_decode_range_dev of the whole graph into int64 in HBM (profiles/mat_bench.py: 8 tiles of a 2^21-node base; outdegree pass + prefix sum included; best of calls 3..6)', 'runs': rows}, open('gpurun_out/r04_mat_bench.json', 'w'), indent=1)"

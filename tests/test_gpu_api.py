@@ -256,6 +256,49 @@ def test_device_index_is_saved_and_loaded_back(W, tools, oracle, tmp_path, capfd
     h.close()
 
 
+def test_a_handle_without_index_neither_builds_nor_reads_one(W, tools, oracle, monkeypatch, capfd):
+    """bvg_tuning.no_index (ABI 3): what bench.py times as `value_no_index`.  A flyweight with it scans index-less -- index_entries 0, no lean blocks, no
+    index-building pass -- next to a handle that builds and uses the index; both equal the oracle, and the flyweight does not disturb the shared index."""
+    monkeypatch.setenv("BVG_DEBUG", "1")
+    st = tools.synth_store(40000, seed=31, synth=tools.eu_like(mean_deg=60.0), threads=4)
+    g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+    o = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets).scan()
+    h = g.copy(); h.set_tuning(no_index=True)
+    capfd.readouterr()
+    for _ in range(2):
+        r = h.scan()
+        assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"]) and r["index_entries"] == 0 and r["lean_blocks"] == 0
+    assert "residual skip index" not in capfd.readouterr().err, "the index-less handle built an index"
+    r1 = g.scan()                                                       # the first scan of the other handle IS the index build (its validating pass reports the result)
+    r2 = g.scan()
+    assert (r1["arcs"], r1["chk"]) == (o["arcs"], o["chk"]) == (r2["arcs"], r2["chk"])
+    assert r1["index_entries"] == r2["index_entries"] > 0 and r2["lean_blocks"] > 0 and r1["lean_blocks"] == 0
+    assert capfd.readouterr().err.count("residual skip index: blocks") == 1
+    r = h.scan()                                                        # still index-less, although the index now exists in the shared graph
+    assert (r["arcs"], r["chk"]) == (o["arcs"], o["chk"]) and r["index_entries"] == 0 and r["lean_blocks"] == 0
+    h.close(); g.close()
+
+
+def test_work_order_and_giant_work_areas_do_not_change_results(W, tools, oracle, monkeypatch):
+    """Round 4's launch-level changes against their round-3 forms: the XCD-aware work order (BVG_XCDS=1: plain order) and the giants' shared work-area slots
+    (BVG_GBATCH=<n>: batched launches with one area per block) -- same {nodes, arcs, chk}, same lists."""
+    st = tools.synth_store(15000, seed=33, synth=tools.eu_like(max_deg=30000, tail_alpha=1.6, mean_deg=40.0), threads=4)
+    og = oracle.Graph.from_memory(oracle.Params(**st.params.as_dict()), st.graph.tobytes(), st.offsets)
+    o = og.scan(); odeg, osucc = og.decode_range(0, 15000)
+    for env in ({}, {"BVG_XCDS": "1"}, {"BVG_GBATCH": "7"}, {"BVG_XCDS": "3", "BVG_GBATCH": "1"}):
+        for k in ("BVG_XCDS", "BVG_GBATCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
+        for _ in range(3):
+            r = g.scan()
+            assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), env
+        deg, succ = g.decode_range(0, 15000)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), env
+        g.close()
+
+
 @pytest.mark.parametrize("shape", ["eu", "heavy_tail", "w0", "gamma_residuals"])
 def test_dense_walk_builds_the_same_index_as_the_one_pass_build(W, tools, oracle, tmp_path, monkeypatch, shape):
     """Round 4 fills the skip entries by a dense walk (csrc/bvg_index.hip: one lane per long list, every coding) and validates the blocks in a pass
