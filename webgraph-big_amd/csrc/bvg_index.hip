@@ -9,8 +9,8 @@
 // Here the walk is its own kernel and it is DENSE: one wavefront per node block parses the record headers of the block row by row
 // (one lane per record: outdegree, reference, copy blocks and intervals only as far as their sums go -- BVG:1010-1060 -- which gives the
 // residual count and where the residual codes start), QUEUES the lists that have entries, and whenever 64 of them are waiting (or the
-// block ends) walks them with one lane per list: every lane of the walk is a long list.  Everything is read straight from the stream in
-// global memory through the generic BitCursor (every legal coding), nothing is emitted, summed or validated: the entries are verified
+// block ends) walks them with one lane per list: every lane of the walk is a long list.  The block's stream is staged in LDS once (8 KiB window;
+// what lies outside it is read from global memory) and read through the generic BitCursor (every legal coding), nothing is emitted, summed or validated: the entries are verified
 // by the pass that follows (the row kernel decoding WITH them, skip_mode 3: an entry that does not lie where the stream says fails its
 // task and leaves the block unvalidated), so a wrong walk can cost speed, never correctness.
 //
@@ -22,6 +22,7 @@ namespace bvg {
 namespace {
 
 constexpr uint32_t RM = kRing - 1;
+constexpr uint32_t kWalkWords = 2048;          // LDS window over the block's stream: 8 KiB (a block is ~4 KiB of stream + its halo)
 
 template <bool GEN> struct Rdi {   // the field readers of bvg_kernels.hip (GEN = false: BVGraph's default codings, straight-line)
     static __device__ __forceinline__ uint64_t outdegree(BitCursor& c, const Codings& k, uint64_t g) { if (GEN) return c.read_coded(k.outdegree, 0, g); return c.read_gamma(g); }
@@ -50,6 +51,23 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
     const int W = a.window;
     const int64_t hs = s - (int64_t)halo;
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) nd_d[i] = 0;
+    // the block's stream (halo included) in LDS, big-endian dwords: a block is ~4 KiB; what does not fit the window is read from global memory (BitCursor::peek)
+    __shared__ __attribute__((aligned(16))) uint32_t win[kWalkWords];
+    uint64_t win_bit0 = 0; uint32_t win_bits = 0;
+    {
+        const uint64_t lo_bit = a.offsets[hs], hi_bit = a.offsets[e];
+        const uint64_t b0 = (lo_bit >> 3) & ~15ull;
+        uint64_t nb = ((hi_bit + 7) >> 3) + 16 > b0 ? ((hi_bit + 7) >> 3) + 16 - b0 : 0;          // (+16: a window read looks 96 bits ahead)
+        nb = (nb + 15) & ~15ull;
+        if (nb > kWalkWords * 4ull) nb = kWalkWords * 4ull;
+        if (b0 + nb > a.padded_bytes) nb = a.padded_bytes > b0 ? (a.padded_bytes - b0) & ~15ull : 0;
+        for (uint32_t c = lane; c < (uint32_t)(nb >> 4); c += 64) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.graph + b0 + ((uint64_t)c << 4));
+            uint4 w; w.x = __builtin_bswap32(v.x); w.y = __builtin_bswap32(v.y); w.z = __builtin_bswap32(v.z); w.w = __builtin_bswap32(v.w);
+            *reinterpret_cast<uint4*>(&win[c << 2]) = w;
+        }
+        win_bit0 = b0 << 3; win_bits = (uint32_t)(nb << 3);
+    }
     __syncthreads();
 
     uint32_t sk_run = 0, qn = 0;
@@ -61,7 +79,7 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
         uint32_t nmax = nres;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(nmax, o, 64); nmax = t > nmax ? t : nmax; }
-        BitCursor cur{a.graph, pos0, a.limit_byte};
+        BitCursor cur{a.graph, pos0, a.limit_byte, win, win_bit0, win_bits, 0u, 0xFFFFFFFFu};
         const uint64_t guard = pos0 + (on ? q_len[lane] : 0u);          // the end of the list's record: a runaway code stops there
         int64_t r = x;
         for (uint32_t t = 0; t < nmax; t++) {
@@ -89,7 +107,7 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
         const bool needed = in_range && (x >= s || ((hmask >> hbit) & 1ull));
         uint64_t off_x = 0, rec_end = 0;
         if (needed) { off_x = a.offsets[x]; rec_end = a.offsets[x + 1]; }
-        BitCursor cur{a.graph, off_x, a.limit_byte};
+        BitCursor cur{a.graph, off_x, a.limit_byte, win, win_bit0, win_bits, 0u, 0xFFFFFFFFu};
         uint32_t d = 0;
         bool ok = needed;
         if (needed) { const uint64_t dv = R::outdegree(cur, a.cod, rec_end); ok = dv <= 0x7FFFFFFFull; d = ok ? (uint32_t)dv : 0u; }
