@@ -159,7 +159,8 @@ int bvg_build_index(bvg_graph* g, int64_t from, int64_t to, uint64_t* entries, u
 /* The device index on disk: the block plan and the residual skip index (with its validation marks) as they stand, written to `path` and
  * loaded back by a later process instead of rebuilt (cf. the reference's cached offsets big list, basename.obl, BVG:1545-1555).
  * bvg_open() loads basename.bvgidx by itself when it exists and is not older than basename.graph; a file that does not belong to
- * the graph (size, parameters, block size, a fingerprint of the stream) is refused with BVG_E_IO and the index is built as usual. */
+ * the graph (format 2: size, every parameter that shapes a record, block size, a hash of EVERY byte of the stream computed on the device) or is damaged (a
+ * checksum over its payload; range checks on every array) is refused with BVG_E_IO and the index is built as usual: the lean kernels trust the marks. */
 int bvg_save_index(bvg_graph* g, const char* path);
 int bvg_load_index(bvg_graph* g, const char* path);
 /* Node-range split points for k shards of ~equal compressed size (the balanced variant of
