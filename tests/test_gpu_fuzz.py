@@ -87,3 +87,4 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
             ref = st if chunk == 0 else tools.store((off, adj), p, chunk_nodes=chunk, threads=2)
             gb, go = W.store((off, adj), p, chunk_nodes=chunk)
             assert np.array_equal(gb, ref.graph) and np.array_equal(go, ref.offsets), what + (chunk,)
+        if case % 100 == 99: print("fuzz: %d of %d cases" % (case + 1, cases), flush=True)      # (long runs: `pytest -s` shows progress)

@@ -708,8 +708,14 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     uint32_t rr = rel;
                     uint32_t jk = 0, joff = 0, jl = kInf, jn = 0;                     // (d2: the next interval, what the passed ones add)
                     if (d2) { jl = (uint32_t)scr[ib]; jn = (uint32_t)scr[ib + 1] & 0xFFFFu; }
+#ifdef BVG_ABLATE_LPN
+                    if (false)
+#endif
                     for (uint32_t t = 0; t < nres; t++) {
                         uint64_t val;
+#ifdef BVG_EXP_DUMMY_LPN
+                        { uint32_t dm = t; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY_LPN; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
+#endif
                         const uint32_t len = read_residual<false>(stage, rr, zfast, zk, a.cod.residual, val);
                         if (len == 0) { bad = true; break; }
                         rr += len;
