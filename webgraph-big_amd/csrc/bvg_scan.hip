@@ -636,63 +636,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                     }
                     BVG_T1(14, tq9p);
-#ifdef BVG_EXP_UNROLL
-#pragma unroll 2
-#endif
-                    for (uint32_t i = 0;; i++) {
-#ifdef BVG_ABLATE_RESLOOP
-                        break;
-#endif
-                        bool on[RU]; bool any = false;
-#pragma unroll
-                        for (uint32_t u = 0; u < RU; u++) { on[u] = i < cnt[u]; any |= on[u]; }
-                        if (!ballot(any)) break;
-                        BVG_WC(7, 1);
-#ifdef BVG_EXP_DUMMY
-                        { uint32_t dm = i; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
-#endif
-#pragma unroll
-                        for (uint32_t u = 0; u < RU; u++) BVG_WCL(8, on[u] ? 1u : 0u);
-                        uint32_t len[RU]; uint64_t val[RU]; bool slow = false;
-                        uint32_t w32[RU];
-#pragma unroll
-                        for (uint32_t u = 0; u < RU; u++) w32[u] = win32<LIN>(stage, trel[u]);   // all chains' LDS reads first: they overlap
-#pragma unroll
-                        for (uint32_t u = 0; u < RU; u++) {
-                            uint32_t v32 = 0; len[u] = Z3 ? zeta3_fast32(w32[u], v32) : (zfast ? zeta_fast32(w32[u], zk, v32) : 0u); val[u] = v32;
-                            slow |= on[u] && len[u] == 0;
-                        }
-                        if (ballot(slow)) {                                   // codes longer than 31 bits (or zeta_1): one rare, wave-uniform detour
-#pragma unroll
-                            for (uint32_t u = 0; u < RU; u++)
-                                if (on[u] && len[u] == 0) {
-                                    len[u] = zeta64(win64<LIN>(stage, trel[u]), zk, val[u]);
-                                    if (len[u] == 0) { tbad = true; cnt[u] = 0; on[u] = false; }
-                                }
-                        }
-#pragma unroll
-                        for (uint32_t u = 0; u < RU; u++) {
-                            const T gap = (tfirst[u] && i == 0) ? (T)nat2int64(val[u]) : (T)(1 + (T)val[u]);
-                            const T rn = (T)(r[u] + gap);
-                            if (WIDE) {                                       // the id must stay inside the block's 2^32 ids
-                                const int64_t tv = (int64_t)(uint64_t)r[u] + ((tfirst[u] && i == 0) ? nat2int64(val[u]) : (int64_t)(1 + val[u]));
-                                tbad |= on[u] && (((uint64_t)tv) >> 32) != 0;
-                            }
-                            const uint32_t tn = trel[u] + len[u];
-                            if (anyd2 && ballot(on[u] && (uint32_t)rn > ivl[u])) {   // this residual passes an interval (or several): it starts right here
-                                while (on[u] && (uint32_t)rn > ivl[u]) {
-                                    scr[tib2[u] + 2 * ivk[u] + 1] = (T)(ivn[u] | ((t0a[u] + i + ioff[u]) << 16));
-                                    ioff[u] += ivn[u]; ivk[u]++;
-                                    if (ivk[u] < tic2[u]) { ivl[u] = (uint32_t)scr[tib2[u] + 2 * ivk[u]]; ivn[u] = (uint32_t)scr[tib2[u] + 2 * ivk[u] + 1] & 0xFFFFu; } else ivl[u] = kInf;
-                                }
-                            }
-                            if (on[u] && taddr[u] != kInf) pool[taddr[u] + i + ioff[u]] = rn;
-                            if (!MAT) csum += mix_node<T>(tk0[u], on[u] ? tk1[u] : 0u, rn, nb_lo, nbz);
-                            r[u] = rn; trel[u] = on[u] ? tn : trel[u];              // (a lane past its task keeps adding to r: nobody reads it)
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < RU; u++) tbad |= trel[u] > tpend[u];    // ran past the record: checked once, behind the loop (reads past it are harmless)
+#include "bvg_scan_steps.inc"
                 }
                 };
 #ifndef BVG_SCAN_RU2_FROM
@@ -702,7 +646,25 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 // and its registers are what the 85-VGPR instantiation of the sparse graphs spills (44 -> 31 spilled VGPRs without it: cnr-2000 +3.4 %, web +2.4 %, profiles/r04_ab_noru2*.txt)
                 if (OCC == 4 && Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
                 bad |= tbad;
-            } else if (rparse) {
+            } else if (OCC == 6 ? ballot(rparse && nres > 0) != 0 : false) {
+                // no list of the sub-row is long enough for skip entries: one task per lane, the residuals of its own node, through the same branch-free
+                // step loop.  Sparse graphs (the 85-VGPR instantiation) only: +1.0 % on cnr-2000, +0.7 % on `web`, 16 instead of 31 spilled registers
+                // (profiles/r04_ab_lpn5_*.txt; as a lambda shared with the task passes +1.6 / +1.9 %, but then the dense instantiations lose 0.5 %:
+                // r04_ab_lpn2_*.txt, r04_ab_lpn4_*.txt); the dense instantiations seldom come here and keep the plain loop below, their code unchanged
+                constexpr uint32_t RU = 1;
+                const bool has = rparse && nres > 0;
+                const bool anyd2 = D2 && OCC <= 5 && ballot(d2 && act) != 0;
+                bool tbad = false;
+                uint32_t cnt[1] = {has ? nres : 0u}, trel[1] = {has ? rel : 0u}, tpend[1] = {has ? pend : 0u}, tfirst[1] = {1u}, tk0[1] = {k0}, tk1[1] = {has ? k1d : 0u};
+                uint32_t taddr[1] = {(has && (stored || gl)) ? ((direct || d2) ? base : rtb) : kInf};
+                T r[1] = {(T)(x - B)};
+                uint32_t ivl[1] = {kInf}, ivn[1] = {0u}, ivk[1] = {0u}, ioff[1] = {0u}, tic2[1] = {0u}, tib2[1] = {0u}, t0a[1] = {0u};
+                if (anyd2 && has && d2) { tic2[0] = ic; tib2[0] = ib; ivl[0] = (uint32_t)scr[ib]; ivn[0] = (uint32_t)scr[ib + 1] & 0xFFFFu; }
+#ifndef BVG_ABLATE_LPN
+#include "bvg_scan_steps.inc"
+#endif
+                bad |= tbad;
+            } else if (OCC != 6 && rparse) {
                 if (nres > 0) {
                     T r = (T)(x - B);
                     uint32_t rr = rel;
