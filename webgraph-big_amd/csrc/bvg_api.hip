@@ -41,8 +41,9 @@ namespace {
 
 constexpr uint32_t kDefaultBlockBits = 32768;   // ~4 KiB of compressed stream per wavefront
 constexpr uint64_t kPad = 64;                   // zero bytes after the stream (8-byte loads + record overruns)
-constexpr uint32_t kGiantResident = 512;        // giant workgroups (1 024 threads) that can be resident at once: 2 per CU
+constexpr uint32_t kGiantResident = 512;        // giant workgroups (512 threads, 88 registers: 2 wavefronts per SIMD each) that can be resident at once: 2 per CU
 constexpr uint32_t kGiantSlots = 768;           // their work areas: half as many again (a free one always turns up)
+static uint32_t giant_slots() { if (knob("BVG_GSLOTS")) { const int v = atoi(knob("BVG_GSLOTS")); if (v >= 1 && v <= 8192) return (uint32_t)v; } return kGiantSlots; }   // (experiments)
 
 // a device allocation freed on every return path
 struct DevBuf {
@@ -818,10 +819,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (ngiant) {
                 // (the giant kernel parks the residuals of the list it decodes in the same area: twice the worst list + window)
                 gpool_elems = 1ull << 16; while (gpool_elems < 2 * pd.giant_need + pd.giant_need / 4) gpool_elems <<= 1;
-                // Work areas: as many SLOTS as giant workgroups can be resident at once (2 per CU: 1 024 threads each) and half as many again, whatever the
+                // Work areas: as many SLOTS as giant workgroups can be resident at once (2 per CU: bvg_giant.hip) and half as many again, whatever the
                 // number of giant blocks -- the kernel takes a free slot when a workgroup starts (DecodeArgs::gslots).  Round 3 sized one area per block of
                 // a batch of 8 192 (up to 1/8 of the free memory: 26-31 GB on the default workload, per handle).  All giants go in ONE launch.
-                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(kGiantSlots, ngiant);
+                gscr_elems = gpool_elems / 2; gbatch = std::min<uint32_t>(giant_slots(), ngiant);
                 if (knob("BVG_GBATCH")) gbatch = (uint32_t)std::max(1, atoi(knob("BVG_GBATCH")));   // (experiments: batched launches, one area per block of a batch)
                 use_slots = !knob("BVG_GBATCH");
                 {
@@ -838,8 +839,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     if (hipMalloc(&g->giant_ws, bytes) == hipSuccess) g->giant_ws_bytes = bytes; else gbatch = 0;   // fall back to the cascade
                 }
                 if (use_slots && gbatch) {
-                    if (!g->d_gslots && hipMalloc(&g->d_gslots, kGiantSlots * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); g->d_gslots = nullptr; use_slots = false; gbatch = std::min<uint32_t>(gbatch, 256u); }
-                    if (use_slots) HIPCHK(hipMemsetAsync(g->d_gslots, 0, kGiantSlots * sizeof(uint32_t), g->stream));   // (ordered before the side streams by ev0 below)
+                    if (!g->d_gslots && hipMalloc(&g->d_gslots, 8192 * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); g->d_gslots = nullptr; use_slots = false; gbatch = std::min<uint32_t>(gbatch, 256u); }
+                    if (use_slots) HIPCHK(hipMemsetAsync(g->d_gslots, 0, 8192 * sizeof(uint32_t), g->stream));   // (ordered before the side streams by ev0 below)
                 }
             }
             HIPCHK(hipEventRecord(g->ev0, g->stream));

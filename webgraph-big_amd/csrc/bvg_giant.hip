@@ -2,7 +2,7 @@
 //
 // Transposed and social graphs have lists of 10^5..10^7 successors.  The generic global-memory kernel (bvg_kernels.hip,
 // decode_kernel<SLOW>) follows the reference's iterators literally with ONE lane per list: ~1 us per successor, so a handful of
-// such lists takes longer than the rest of the graph.  Here one workgroup of 1024 threads walks its block node by node and
+// such lists takes longer than the rest of the graph.  Here one workgroup of GNT = 512 threads walks its block node by node and
 // every node is decoded by the whole workgroup, everything in a per-workgroup area of global memory:
 //   * the counts of the record header (BVG:1003-1021, 1040) are decoded by wavefront 0 in step, on the scalar unit, from a register
 //     bit buffer over a sliding LDS window of the stream;
@@ -15,7 +15,7 @@
 //     with v_readlane, and prefix scans over its lanes turn up to 64 gaps per step into values (sections under 48 codes: in step);
 //   * the list is put together by output POSITION as in the row kernels (bvg_rows.hip): every extra (interval, residual) finds
 //     its place by binary searches (extras below it + copied elements below it: lower bound in the referenced list, rank under
-//     the copy mask), then 1024 equal tasks of consecutive positions fill in the kept elements of the referenced list
+//     the copy mask), then GNT equal tasks of consecutive positions fill in the kept elements of the referenced list
 //     (MaskedLongIterator.java:73-100) and the interval elements (LongIntervalSequenceIterator.java:71-78).
 // Streams whose three parts overlap (MergedLongIterator.java:85-89 would emit the value once), counts that contradict each other,
 // non-default codings and windows > 64 fail over to decode_kernel<SLOW>; a work area that is too small is reported as such and
@@ -28,7 +28,19 @@ using namespace rows;
 
 namespace {
 
-constexpr unsigned GNT = 1024;               // threads per workgroup: the phases that walk global memory are latency-bound, 16 wavefronts hide 4x what 4 do
+// Threads per workgroup.  The phases that walk global memory are latency-bound and 16 wavefronts hide 4x what 4 do -- but a giant workgroup shares its
+// CU with the lean scan kernel, whose wavefronts take 128 registers: 1 024 threads at 99 (104 allocated) registers are 416 of a SIMD's 512, so ONE giant
+// workgroup kept every tier-0 wavefront off its CU for its 240 us (most of them spent on the ~15 ordinary nodes behind the large list, at 5 % vector
+// activity): the 0.3 % of the default workload's blocks that are giants held 9 % of the chip.  512 threads at 88 registers leave room for two tier-0
+// wavefronts per SIMD next to a giant: 251 -> 273 G edges/s on the default workload (256 / 384 / 512 threads: 272.6 / 272.2 / 273.7; 128: 258; 64: 229;
+// 1 024 threads squeezed into 64 / 80 registers: 269.7 / 268.4; profiles/r04_ab_giantwg*.txt).
+#ifndef BVG_GIANT_THREADS
+#define BVG_GIANT_THREADS 512
+#endif
+#ifndef BVG_GIANT_MINWG
+#define BVG_GIANT_MINWG 1                    // (experiments: minimum wavefronts per SIMD, i.e. a register budget)
+#endif
+constexpr unsigned GNT = BVG_GIANT_THREADS;
 constexpr uint32_t kGStageWords = 2048;      // LDS window over the stream: 8 KiB
 constexpr uint32_t kHdrMin = 48;             // copy-block / interval sections this long get index entries (one per kSkipEvery codes)
 typedef MaskPrefix<uint64_t> MP;
@@ -81,7 +93,7 @@ __device__ __forceinline__ uint32_t upper_bound64(const uint64_t* arr, uint32_t 
 #endif
 
 template <typename T, bool MAT>
-__global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
+__global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs a) {
 #ifdef BVG_PROF
     long long gp_t[7] = {0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -672,7 +684,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
         }
         __syncthreads();
         GP_T(5);
-        // Z2: 1024 equal tasks of consecutive output positions
+        // Z2: GNT equal tasks of consecutive output positions
         {
             uint32_t S = (d + GNT - 1u) / GNT; if (S < kMinTask) S = kMinTask;
             uint32_t p = tid * S, pstop = p + S < d ? p + S : d;
@@ -757,7 +769,7 @@ __global__ void __launch_bounds__(GNT) giant_kernel(DecodeArgs a) {
 
 }  // namespace
 
-// scan / materialise the blocks of the work list with one 1024-thread workgroup each; a.gpool / a.gscr: per-workgroup areas as for
+// scan / materialise the blocks of the work list with one GNT-thread workgroup each; a.gpool / a.gscr: per-workgroup areas as for
 // decode_kernel<SLOW>.  Default codings and windows <= kMaxWindow only (the caller checks).
 static const size_t giant_pad_default = 0;
 void launch_giant_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s) {
