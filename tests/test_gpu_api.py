@@ -326,6 +326,45 @@ def test_dense_walk_builds_the_same_index_as_the_one_pass_build(W, tools, oracle
     assert files["0"][0] == files[None][0], "the two builds left different index files"
 
 
+@pytest.mark.parametrize("shape", ["dense", "sparse", "w0"])
+def test_the_skip_index_granularity_is_a_property_of_the_index(W, tools, oracle, tmp_path, monkeypatch, shape):
+    """Round 4 chooses the granularity of the residual skip index per graph (csrc/bvg_api.hip skip_granularity: one entry per 8 residuals from lists of 8 on
+    for graphs with references below 40 arcs per node, per 16 from 16 on otherwise; rounds 1-3: per 16 from 24 on); the kernels take it from the index they
+    are handed, and basename.bvgidx carries it.  Every granularity
+    must give the oracle's scan and materialise (first scan = the build, second = the lean kernel on validated blocks); an index saved under one
+    granularity must load and work in a process that would have chosen another; finer granularities hold more entries."""
+    synth, n, kw = tools.eu_like(mean_deg=70.0), 40000, {}
+    if shape == "sparse": synth, n = tools.web_like(mean_deg=11.0), 150000
+    if shape == "w0": synth, n, kw = tools.web_like(mean_deg=30.0), 60000, dict(window_size=0, max_ref_count=0, min_interval_length=0)
+    st = tools.synth_store(n, seed=29, params=W.default_params(**kw), synth=synth, threads=4)
+    base = str(tmp_path / "g"); st.write(base)
+    og = oracle.Graph.load(base); o = og.scan()
+    entries, saved = {}, None
+    for gran in (None, "24,16", "16,16", "8,8", "4,4", "9,2", "40,64"):
+        if gran is None: monkeypatch.delenv("BVG_SKIP_GRAN", raising=False)
+        else: monkeypatch.setenv("BVG_SKIP_GRAN", gran)
+        g = W.BVGraph.load(base)
+        for _ in range(2):
+            r = g.scan()
+            assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), (shape, gran)
+        assert r["lean_blocks"] > 0, (shape, gran)
+        a, b = n // 3, n // 3 + 5000
+        deg, succ = g.decode_range(a, b)
+        odeg, osucc = og.decode_range(a, b)
+        assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc), (shape, gran)
+        entries[gran] = r["index_entries"]
+        if gran == "4,4": saved = g.save_index(str(tmp_path / "idx44"))
+        g.close()
+    assert entries["4,4"] > entries["8,8"] > entries["16,16"] > entries["24,16"] > entries["40,64"], entries
+    assert entries[None] == (entries["8,8"] if shape == "sparse" else entries["16,16"]), (shape, entries)       # the per-graph choice
+    monkeypatch.setenv("BVG_SKIP_GRAN", "24,16")                              # this process would build 24 / 16: the file's 4 / 4 entries are used as they are
+    g = W.BVGraph.load(base)
+    g.load_index(saved)
+    r = g.scan()
+    assert (r["arcs"], r["chk"], r["index_entries"]) == (o["arcs"], o["chk"], entries["4,4"]) and r["lean_blocks"] > 0
+    g.close()
+
+
 def test_a_damaged_or_foreign_index_file_is_refused(W, tools, oracle, tmp_path):
     """The lean scan kernel trusts the validation marks of basename.bvgidx, so the file is tied to EVERY byte of the stream and guarded
     by a checksum of its own payload (format 2): a .graph rewritten in place with the same size and other bytes in the middle, a

@@ -62,6 +62,7 @@ struct SkipIndex {
     uint32_t blk_lo = 0, blk_hi = 0;
     uint64_t total = 0; uint64_t* d_first = nullptr; uint16_t* d_bit = nullptr; void* d_val = nullptr; uint8_t* d_fmt = nullptr;
     bool wide = false;                        // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
+    uint32_t skip_min = kSkipMin, skip_shift = 4;   // granularity: lists of >= skip_min residuals hold one entry per 2^skip_shift residuals (skip_granularity() when it is built)
     bool failed = false;                      // the build of [blk_lo, blk_hi) failed (out of memory, malformed stream): no arrays; scans of those blocks run index-less and
                                               // do NOT try again on their own (only bvg_build_index does)
     uint64_t gen = 0;                         // identity of this snapshot: what a handle learned about blocks (tier lists, lean / row split) holds for ONE snapshot only
@@ -392,6 +393,24 @@ struct BatchPlan { const uint64_t* d_first; const uint32_t* d_halo; const uint64
 int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const uint64_t* d_cum, int64_t* d_succ, int32_t* d_outdeg,
                bvg_scan_result* res, const BatchPlan* batch = nullptr, const std::shared_ptr<Plan>* use_plan = nullptr);
 
+// The granularity of a graph's skip index: lists of >= `smin` residuals hold one entry per 2^shift residuals.  A residual pass lasts as long as its longest task, so the
+// threshold matters as much as the spacing: 16 / 16 (a list of 16-23 residuals is two tasks instead of one of up to 23 steps) gains on every shape over rounds 1-3's 24 / 16
+// -- w0 +7.2 %, uk +3.8 %, web +2.6 %, eu +1.5 %, eu15 +1.0 % -- for 0.1-8 % more entries.  A sparse graph's pass holds few tasks, and one entry per 8 residuals from
+// lists of 8 on shortens it further: web +11.5 %, uk +5.1 %, cnr-2000 +2.3 % over 24 / 16, for 0.1-0.3 GB of entries per GB of stream; on the dense default workload 8 / 8
+// is no faster than 16 / 16 and takes +80 % of an index that is half the stream already, on the reference-free w0 neither (its lists are residuals only: +30 % of resident
+// bytes) -- profiles/r04_skipgran3.txt.  So: 8 / 8 below 40 arcs per node (128 bits per node when the arc count is unknown) when the graph has references, else 16 / 16.
+// BVG_SKIP_GRAN="min,every" (test knob) overrides; the kernels take the granularity from the index they are handed (DecodeArgs::skip_min / skip_shift), the file carries it.
+static void skip_granularity(const Shared* sh, uint32_t& smin, uint32_t& shift) {
+    smin = kSkipMin; shift = 0; while ((1u << shift) < kSkipEvery) shift++;
+    const double nodes = (double)std::max<int64_t>(sh->p.nodes, 1);
+    const bool sparse = sh->p.arcs > 0 ? (double)sh->p.arcs / nodes < 40.0 : (double)sh->total_bits / nodes < 128.0;
+    if (sparse && sh->p.window_size > 0) { smin = 8; shift = 3; }
+    if (knob("BVG_SKIP_GRAN")) {
+        unsigned m = 0, e = 0;
+        if (sscanf(knob("BVG_SKIP_GRAN"), "%u,%u", &m, &e) == 2 && m >= 2 && m <= 4096 && e >= 2 && e <= 64 && (e & (e - 1)) == 0) { smin = m; shift = 0; while ((1u << shift) < e) shift++; }
+    }
+}
+
 // Residual skip index: nodes with long residual lists get one entry per kSkipEvery residuals, so the row kernel can decode a
 // long list as independent segments on otherwise idle lanes.  Two passes of the ordinary decode over the plan blocks [blo, bhi):
 // count the entries of every block, prefix-sum on the host, fill.  An index, not a cache: every gap is still decoded from the stream.
@@ -415,6 +434,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     const bool build_wide = sh->wide || g->tun.force_wide;
     std::shared_ptr<SkipIndex> ix = std::make_shared<SkipIndex>();
     ix->device = sh->device; ix->blk_lo = blo; ix->blk_hi = bhi; ix->wide = build_wide; ix->gen = next_plan_version();
+    skip_granularity(sh, ix->skip_min, ix->skip_shift);
     auto publish = [&]() { std::atomic_store(&pl.skip, ix); return 0; };
     // no index: the scans run without one.  The failure is PUBLISHED (an empty snapshot of the same block range, unless a good index of
     // other blocks exists already), so that later scans of these blocks do not pay the counting pass again and again; bvg_build_index() retries.
@@ -433,9 +453,9 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     const auto tb0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count(); };
     if (cnt_d.alloc((size_t)nblk * sizeof(uint32_t)) || hipMemset(cnt_d.p, 0, (size_t)nblk * sizeof(uint32_t)) != hipSuccess) return give_up();
-    g->skip_mode = 1; g->skip_cnt = (uint32_t*)cnt_d.p;
+    g->skip_mode = 1; g->skip_cnt = (uint32_t*)cnt_d.p; g->skip_building = ix;          // (the counting pass counts in the new index's granularity)
     int r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
-    g->skip_mode = 0; g->skip_cnt = nullptr;
+    g->skip_mode = 0; g->skip_cnt = nullptr; g->skip_building.reset();
     const double t_count = since();
     std::vector<uint32_t> cnt(nblk);
     if (!r && hipMemcpy(cnt.data(), cnt_d.p, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
@@ -461,7 +481,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
         wa.graph = sh->d_graph; wa.limit_byte = sh->nbytes; wa.padded_bytes = sh->padded; wa.offsets = sh->offs; wa.n = sh->p.nodes; wa.from = nfrom; wa.to = nto;
         wa.blk_first = pl.d_first; wa.blk_halo = pl.d_halo; wa.blk_mask = pl.d_mask; wa.work_list = nullptr; wa.blk_lo = blo;
         wa.window = sh->p.window_size; wa.min_interval = sh->p.min_interval_length; wa.cod = codings_of(sh->p);
-        wa.skip_first = ix->d_first; wa.skip_bit = ix->d_bit; wa.skip_val = ix->d_val;
+        wa.skip_first = ix->d_first; wa.skip_bit = ix->d_bit; wa.skip_val = ix->d_val; wa.skip_min = ix->skip_min; wa.skip_shift = ix->skip_shift;
         launch_index_walk(wa, bhi - blo, build_wide, g->stream);
         if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up();
         t_walk = since();
@@ -562,6 +582,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         a.pass_cost = knob("BVG_PASSCOST") ? (uint32_t)strtoul(knob("BVG_PASSCOST"), nullptr, 10) : 10u;   // measured: 11-14 merge steps per level pass; the optimum of the estimate is flat over 8-14
     }
     a.skip_mode = (uint32_t)g->skip_mode; a.skip_cnt = g->skip_cnt;
+    {   // the granularity of the index in use -- or of the one being built: the counting pass has no arrays yet
+        const SkipIndex* gi = g->skip_mode == 1 ? g->skip_building.get() : skx.get();
+        a.skip_min = gi ? gi->skip_min : kSkipMin; a.skip_shift = 0; if (gi) a.skip_shift = gi->skip_shift; else while ((1u << a.skip_shift) < kSkipEvery) a.skip_shift++;
+    }
     a.xcds = knob("BVG_XCDS") ? (uint32_t)std::max(1, atoi(knob("BVG_XCDS"))) : 8u;
     a.wide_half = knob("BVG_WIDE_HALF") ? strtoull(knob("BVG_WIDE_HALF"), nullptr, 10) : 0x80000000ull;
     if (!batch && rows_default && skx && skx->wide == wide) {
@@ -1231,7 +1255,7 @@ static void fill_header_params(const Shared* sh, IndexHeader& h) {
     h.graph_bytes = sh->nbytes; h.total_bits = sh->total_bits; h.nodes = sh->p.nodes; h.window = (uint32_t)sh->p.window_size;
     h.min_interval = sh->p.min_interval_length; h.zeta_k = sh->p.zeta_k; h.cod_outdegree = sh->p.outdegree_coding; h.cod_block = sh->p.block_coding;
     h.cod_residual = sh->p.residual_coding; h.cod_reference = sh->p.reference_coding; h.cod_block_count = sh->p.block_count_coding;
-    h.skip_min = kSkipMin; h.skip_every = kSkipEvery;
+    h.skip_min = kSkipMin; h.skip_every = kSkipEvery;          // (the index's own granularity when the file holds one: save / load)
 }
 static bool put_dev(FILE* f, const void* d, size_t bytes) {               // device array -> file, in pieces
     std::vector<uint8_t> buf(std::min<size_t>(bytes ? bytes : 1, (size_t)64 << 20));
@@ -1265,7 +1289,7 @@ static int save_index_impl(bvg_graph* g, const char* path) {
     h.nblk = pl.nblk;
     const size_t nb = pl.nblk;
     if (pl.h_maxd.size() != nb) return BVG_E_STATE;
-    if (ix) { h.has_skip = 1; h.wide = ix->wide ? 1u : 0u; h.skip_lo = ix->blk_lo; h.skip_hi = ix->blk_hi; h.skip_total = ix->total; }
+    if (ix) { h.has_skip = 1; h.wide = ix->wide ? 1u : 0u; h.skip_lo = ix->blk_lo; h.skip_hi = ix->blk_hi; h.skip_total = ix->total; h.skip_min = ix->skip_min; h.skip_every = 1u << ix->skip_shift; }
     {   // payload checksum: the arrays in file order
         uint64_t acc = 0, part = 0;
         acc = fold_hash(acc, host_hash(pl.h_first.data(), (nb + 1) * 8), 1); acc = fold_hash(acc, host_hash(pl.h_maxd.data(), nb * 4), 2);
@@ -1306,7 +1330,8 @@ static int load_index_impl(bvg_graph* g, const char* path) {
     fill_header_params(sh, want);
     if (h.graph_bytes != want.graph_bytes || h.total_bits != want.total_bits || h.nodes != want.nodes || h.window != want.window || h.min_interval != want.min_interval ||
         h.zeta_k != want.zeta_k || h.cod_outdegree != want.cod_outdegree || h.cod_block != want.cod_block || h.cod_residual != want.cod_residual ||
-        h.cod_reference != want.cod_reference || h.cod_block_count != want.cod_block_count || h.skip_min != want.skip_min || h.skip_every != want.skip_every ||
+        h.cod_reference != want.cod_reference || h.cod_block_count != want.cod_block_count ||
+        h.skip_min < 2u || h.skip_min > 4096u || h.skip_every < 2u || h.skip_every > 64u || (h.skip_every & (h.skip_every - 1u)) != 0 ||      // (the granularity is the file's own: any valid one)
         h.block_bits != block_bits_of(g) || h.nblk == 0 || (uint64_t)h.nblk > (uint64_t)sh->p.nodes || h.wide > 1u || h.has_skip > 1u) return BVG_E_IO;
     // sizes first: the file must hold exactly what the header promises (and the entry count must be one the stream could produce)
     const size_t nb = h.nblk;
@@ -1347,6 +1372,7 @@ static int load_index_impl(bvg_graph* g, const char* path) {
     if (h.has_skip) {
         ix = std::make_shared<SkipIndex>();
         ix->device = sh->device; ix->blk_lo = h.skip_lo; ix->blk_hi = h.skip_hi; ix->total = h.skip_total; ix->wide = h.wide != 0; ix->gen = next_plan_version();
+        ix->skip_min = h.skip_min; ix->skip_shift = 0; while ((1u << ix->skip_shift) < h.skip_every) ix->skip_shift++;
         ix->h_first.resize(nb + 1); ix->h_fmt.resize(nb);
         if (fread(ix->h_first.data(), 8, nb + 1, f) != nb + 1 || fread(ix->h_fmt.data(), 1, nb, f) != nb) return BVG_E_IO;
         if (ix->h_first[0] != 0 || ix->h_first[nb] != ix->total) return BVG_E_IO;

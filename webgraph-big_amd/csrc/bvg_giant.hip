@@ -42,7 +42,7 @@ namespace {
 #endif
 constexpr unsigned GNT = BVG_GIANT_THREADS;
 constexpr uint32_t kGStageWords = 2048;      // LDS window over the stream: 8 KiB
-constexpr uint32_t kHdrMin = 48;             // copy-block / interval sections this long get index entries (one per kSkipEvery codes)
+constexpr uint32_t kHdrMin = 48, kHdrEvery = 16;   // copy-block / interval sections this long get index entries, one per kHdrEvery codes (whatever the residuals' granularity)
 typedef MaskPrefix<uint64_t> MP;
 
 __device__ __forceinline__ uint32_t gword_be(const uint8_t* g, uint64_t w) { return __builtin_bswap32(reinterpret_cast<const uint32_t*>(g)[w]); }
@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
     const uint64_t SCR = a.gscr_elems * sizeof(T) / sizeof(uint64_t);
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
+    const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
     const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
     const bool nbz = a.node_base == 0;
 
@@ -244,8 +245,8 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
         bool bad = false;
         GP_T(0);
         // ---------------------------------------------------------------- header (BVG:1003-1058) in stages: the counts by wavefront 0 in
-        // step; the copy blocks and the intervals in parallel tasks of kSkipEvery codes when the index holds their entries (every
-        // kSkipEvery-th block / interval of a long section: bit offset + the running sums), else by wavefront 0 in step as well
+        // step; the copy blocks and the intervals in parallel tasks of kHdrEvery codes when the index holds their entries (every
+        // kHdrEvery-th block / interval of a long section: bit offset + the running sums), else by wavefront 0 in step as well
         uint32_t d = 0, ref = 0, bc = 0, ic = 0, nres = 0, rlen = 0, ivtot = 0;
         uint64_t rlb = 0;
         // H1: outdegree, reference, block count
@@ -278,14 +279,14 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
         if (ref > 0) { rlen = uni32(nd_d[(uint32_t)(x - ref) & RM]); rlb = uni64(nd_base[(uint32_t)(x - ref) & RM]); }
         int64_t extra = d;
         // H2: copy blocks (BVG:1023-1032) in prefix form
-        const uint32_t Eb = bc >= kHdrMin ? (bc - 1u) / kSkipEvery : 0u;       // index entries of this section: 6 slots each
+        const uint32_t Eb = bc >= kHdrMin ? (bc - 1u) / kHdrEvery : 0u;       // index entries of this section: 6 slots each
         const uint32_t eb_first = sk_run; sk_run += 6u * Eb;
         if (sk_use && sk_run > sk_slots) { failed = true; GP_WHY(2); break; }             // index out of step with the stream
         if (bc) {
             __syncthreads();                                                   // (hd is rewritten)
             if (sk_use && Eb) {
                 for (uint32_t q = tid; q <= Eb; q += GNT) {
-                    const uint32_t i0 = q * kSkipEvery, cnt = q == Eb ? bc - i0 : kSkipEvery;
+                    const uint32_t i0 = q * kHdrEvery, cnt = q == Eb ? bc - i0 : kHdrEvery;
                     uint64_t pos = cur, tot = 0, cop = 0;
                     if (q) { const uint64_t sl = sk_base + eb_first + 6ull * (q - 1u); pos = off_x + rd32(sl); tot = rd32(sl + 2); cop = rd32(sl + 4); if (!(pos > cur && pos < rec_end)) { bad = true; pos = cur; } }
                     for (uint32_t i = 0; i < cnt && !bad; i++) {
@@ -319,8 +320,8 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                         if (on) {
                             const uint64_t t = tot + ti, c = copied + ci;
                             scr[gi] = MP::pack((uint32_t)t, (uint32_t)c);
-                            if (sk_fill && Eb && gi && (gi & (kSkipEvery - 1u)) == 0) {
-                                const uint64_t sl = sk_base + eb_first + 6ull * (gi / kSkipEvery - 1u), rel = cur + lane - off_x;
+                            if (sk_fill && Eb && gi && (gi & (kHdrEvery - 1u)) == 0) {
+                                const uint64_t sl = sk_base + eb_first + 6ull * (gi / kHdrEvery - 1u), rel = cur + lane - off_x;
                                 if (sl + 5 < sk_base + sk_slots) { wr32(sl, (uint32_t)rel); wr32(sl + 2, (uint32_t)(t - bv)); wr32(sl + 4, (uint32_t)(c - ev)); }
                                 if (rel > 0xFFFFFFFFull) lbad = true;
                             }
@@ -334,8 +335,8 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                 // (the loop is bounded by the count, which the record's length bounds: running off the record's end is checked behind it,
                 // so that the loop-carried chain stays on the scalar unit -- 64-bit comparisons are vector operations)
                 for (uint32_t i = 0; i < bc; i++) {
-                    if (sk_fill && Eb && i && (i & (kSkipEvery - 1u)) == 0 && lane == 0) {
-                        const uint64_t sl = sk_base + eb_first + 6ull * (i / kSkipEvery - 1u);
+                    if (sk_fill && Eb && i && (i & (kHdrEvery - 1u)) == 0 && lane == 0) {
+                        const uint64_t sl = sk_base + eb_first + 6ull * (i / kHdrEvery - 1u);
                         if (sl + 5 < sk_base + sk_slots) { wr32(sl, (uint32_t)(cur - off_x)); wr32(sl + 2, (uint32_t)tot); wr32(sl + 4, (uint32_t)copied); }
                         if (cur - off_x > 0xFFFFFFFFull) bad = true;
                     }
@@ -377,14 +378,14 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
             if (wv != 0) cur = ((uint64_t)uni32(hd[8]) << 32) | uni32(hd[7]);
         }
         // H4: intervals (BVG:1042-1058)
-        const uint32_t Ei = ic >= kHdrMin ? (ic - 1u) / kSkipEvery : 0u;       // 8 slots each
+        const uint32_t Ei = ic >= kHdrMin ? (ic - 1u) / kHdrEvery : 0u;       // 8 slots each
         const uint32_t ei_first = sk_run; sk_run += 8u * Ei;
         if (sk_use && sk_run > sk_slots) { failed = true; GP_WHY(7); break; }
         if (ic) {
             __syncthreads();
             if (sk_use && Ei) {
                 for (uint32_t q = tid; q <= Ei; q += GNT) {
-                    const uint32_t i0 = q * kSkipEvery, cnt = q == Ei ? ic - i0 : kSkipEvery;
+                    const uint32_t i0 = q * kHdrEvery, cnt = q == Ei ? ic - i0 : kHdrEvery;
                     uint64_t pos = cur, before = 0; int64_t prev = 0;
                     if (q) {
                         const uint64_t sl = sk_base + ei_first + 8ull * (q - 1u);
@@ -437,8 +438,8 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                         if (isgap) {
                             if (gc == 0 && S < 0) lbad = true;
                             scr[ib + iv] = (uint64_t)(T)S; scr[ib + ic + iv] = Bf;
-                            if (sk_fill && Ei && iv && (iv & (kSkipEvery - 1u)) == 0) {
-                                const uint64_t sl = sk_base + ei_first + 8ull * (iv / kSkipEvery - 1u), rel = cur + lane - off_x; const uint64_t pv = (uint64_t)(S - c);
+                            if (sk_fill && Ei && iv && (iv & (kHdrEvery - 1u)) == 0) {
+                                const uint64_t sl = sk_base + ei_first + 8ull * (iv / kHdrEvery - 1u), rel = cur + lane - off_x; const uint64_t pv = (uint64_t)(S - c);
                                 if (sl + 7 < sk_base + sk_slots) { wr32(sl, (uint32_t)rel); wr32(sl + 2, (uint32_t)pv); wr32(sl + 4, (uint32_t)(pv >> 32)); wr32(sl + 6, (uint32_t)Bf); }
                                 if (rel > 0xFFFFFFFFull) lbad = true;
                             }
@@ -450,8 +451,8 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                     seek(cur);
                 } else
                 for (uint32_t i = 0; i < ic; i++) {
-                    if (sk_fill && Ei && i && (i & (kSkipEvery - 1u)) == 0 && lane == 0) {
-                        const uint64_t sl = sk_base + ei_first + 8ull * (i / kSkipEvery - 1u);
+                    if (sk_fill && Ei && i && (i & (kHdrEvery - 1u)) == 0 && lane == 0) {
+                        const uint64_t sl = sk_base + ei_first + 8ull * (i / kHdrEvery - 1u);
                         if (sl + 7 < sk_base + sk_slots) { wr32(sl, (uint32_t)(cur - off_x)); wr32(sl + 2, (uint32_t)(uint64_t)prev); wr32(sl + 4, (uint32_t)((uint64_t)prev >> 32)); wr32(sl + 6, (uint32_t)before); }
                         if (cur - off_x > 0xFFFFFFFFull) bad = true;
                     }
@@ -478,7 +479,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
         }
         if (d > 0) nres = (uint32_t)extra;
         if (wv == 0 && nres && !(sk_use && nres >= kSkipMin)) seek(cur);        // the residuals follow in step: wavefront 0's buffer goes back to the cursor
-        const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) / kSkipEvery : 0u;    // index entries of the residuals: 2 slots (+ a value) each
+        const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) >> kSkipShift : 0u;    // index entries of the residuals: 2 slots (+ a value) each
         const uint32_t efirst = sk_run;
         sk_run += 2u * cntE;
         if (a.skip_mode == 1) {                                                 // the index build only counts entries here: the header walk was all it needs
@@ -530,7 +531,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += GNT) {
                     const uint32_t q = p0 + tid;
                     if (q < Ttot) {
-                        const uint32_t t0 = q * kSkipEvery;
+                        const uint32_t t0 = q << kSkipShift;
                         uint32_t cnt = q == cntE ? nres - t0 : kSkipEvery;
                         uint64_t pos = cur; T r = (T)x;
                         if (q) {
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                             const T rv = (T)(r + (T)S);
                             rt[gt] = rv;
                             if (sk_fill && cntE && gt && (gt & (kSkipEvery - 1u)) == 0) {
-                                const uint64_t sl = sk_base + efirst + 2ull * (gt / kSkipEvery - 1u), rel = cur + lane - off_x;
+                                const uint64_t sl = sk_base + efirst + 2ull * ((gt >> kSkipShift) - 1u), rel = cur + lane - off_x;
                                 if (sl + 1 < sk_base + sk_slots) {
                                     wr32(sl, (uint32_t)rel);
                                     const T before_v = (T)(rv - (T)c);
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                 } else
                 for (uint32_t t = 0; t < nres; t++) {
                     if (sk_fill && cntE && t && (t & (kSkipEvery - 1u)) == 0 && lane == 0) {
-                        const uint64_t sl = sk_base + efirst + 2ull * (t / kSkipEvery - 1u);
+                        const uint64_t sl = sk_base + efirst + 2ull * ((t >> kSkipShift) - 1u);
                         if (sl + 1 < sk_base + sk_slots) {
                             const uint64_t rel = cur - off_x;
                             a.skip_bit[sl] = (uint16_t)(rel & 0xFFFFu); a.skip_bit[sl + 1] = (uint16_t)((rel >> 16) & 0xFFFFu);

@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
     __shared__ uint32_t q_lo[64], q_hi[64], q_rec[64], q_nres[64], q_ent[64], q_x[64], q_len[64];   // the waiting lists: start of the residual codes (bit), its distance
                                                                                         // from the record start, residuals, first entry, node (relative to hs)
     const unsigned lane = threadIdx.x;
+    const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
     const uint32_t bid = a.work_list ? a.work_list[blockIdx.x] : (a.blk_lo + blockIdx.x);
     const int64_t s = (int64_t)a.blk_first[bid], e = (int64_t)a.blk_first[bid + 1];
     if (e <= a.from || s >= a.to || s >= e) return;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
         for (uint32_t t = 0; t < nmax; t++) {
             if (t < nres) {
                 if (t && (t & (kSkipEvery - 1u)) == 0) {                // the entry of this residual: where its code starts, what came before it
-                    const uint32_t ei = ent + t / kSkipEvery - 1u;
+                    const uint32_t ei = ent + (t >> kSkipShift) - 1u;
                     if (ei < sk_n) {
                         const uint64_t rel = cur.pos - pos0 + recoff;
                         a.skip_bit[sk_base + ei] = (uint16_t)(rel < 0xFFFFull ? rel : 0xFFFFull);      // (0xFFFF: unusable, the reader fails over)
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(64) index_walk_kernel(DecodeArgs a) {
             }
             nres = ok ? (uint32_t)extra : 0u;
         }
-        const uint32_t cntE = (needed && d > 0 && ok && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
+        const uint32_t cntE = (needed && d > 0 && ok && nres >= kSkipMin) ? (nres - 1u) >> kSkipShift : 0u;
         uint32_t eincl = cntE;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(eincl, o, 64); if ((int)lane >= o) eincl += t; }

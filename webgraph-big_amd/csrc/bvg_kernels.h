@@ -17,7 +17,7 @@ inline bool dbg_on() { static const bool on = getenv("BVG_DEBUG") != nullptr; re
 
 // LDS geometry of the fast (one wavefront per node block) decode kernel.
 #ifndef BVG_SKIP_MIN
-#define BVG_SKIP_MIN 24
+#define BVG_SKIP_MIN 16
 #endif
 #ifndef BVG_SKIP_EVERY
 #define BVG_SKIP_EVERY 16
@@ -95,6 +95,8 @@ struct DecodeArgs {
     const uint64_t* skip_first;         // nblk+1 entry indices, or nullptr
     uint16_t* skip_bit; void* skip_val; // entries: 16-bit bit offset (a record that uses the index fits the LDS window, <= 64 Kbit) + one successor-typed value (4 or 8 bytes)
     uint32_t* skip_cnt;                 // skip_mode 1: per-block entry count out
+    uint32_t skip_min, skip_shift;      // the granularity of THIS index: lists of >= skip_min residuals hold one entry per 2^skip_shift residuals (chosen per graph when the index
+                                        // is built, bvg_api.hip skip_granularity; kSkipMin / kSkipEvery are the dense graphs' values and what a scan without index is handed)
     uint8_t* skip_fmt;                  // per block: who filled its entries (skip_mode 2) -- 1 = row kernels (one slot per entry), 2 = the giant
                                         // kernel (two slots per entry: 32-bit offsets); a kernel uses only entries of its own format
     uint32_t skip_mode;

@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = !GEN && zk >= 2;
+    const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
     const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
     const bool nbz = a.node_base == 0;
     constexpr bool LEAN = !MAT;                              // scan mode: unreferenced lists are not materialised
@@ -347,7 +348,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const uint32_t recrel = (uint32_t)(off_x - stg_bit0);
         uint32_t cntE = 0, efirst = 0;
         if (sk_track) {                                                       // skip entries of the row, in node order
-            cntE = (parse && lane < k && !bad && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
+            cntE = (parse && lane < k && !bad && nres >= kSkipMin) ? (nres - 1u) >> kSkipShift : 0u;
             const uint32_t eincl = wave_incl_scan32(cntE);
             efirst = sk_run + eincl - cntE;
             sk_run += lane_get(eincl, 63);
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             // long tasks first (full segments and tails of more than kShortTask gaps), the short tails after them: a pass of 64
             // tasks lasts as long as its longest one, so like goes with like
             const bool hasres = parse && lane < k && nres > 0 && !bad;
-            const uint32_t lastc = nres - cntE * kSkipEvery;
+            const uint32_t lastc = nres - (cntE << kSkipShift);
             const bool shortt = hasres && lastc <= kShortTask;
             const uint32_t Tn = hasres ? cntE + (shortt ? 0u : 1u) : 0u;           // long tasks of this node
             const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
@@ -386,8 +387,8 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
                     const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
                     const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(rdst, nl, 64), t_ef = __shfl(efirst, nl, 64);
-                    const uint32_t t0 = q * kSkipEvery;
-                    const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
+                    const uint32_t t0 = q << kSkipShift;
+                    const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) >> kSkipShift : 0u;      // the node's entries
                     cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
                     trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)(r0 + nl); tpend[u] = t_pend;
                     tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
@@ -466,7 +467,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                 T r = (T)x;
                 for (uint32_t t = 0; t < nres; t++) {
                     if (a.skip_mode == 2 && cntE && t && (t & (kSkipEvery - 1u)) == 0) {  // fill the skip entry of this residual
-                        const uint32_t ei = efirst + (t / kSkipEvery) - 1u;                // inside the block's allotment only: a block
+                        const uint32_t ei = efirst + (t >> kSkipShift) - 1u;                // inside the block's allotment only: a block
                         if (ei < sk_n) {                                                    // that ends in the generic kernel has none
                             a.skip_bit[sk_base + ei] = (uint16_t)(rel - recrel < 0xFFFFu ? rel - recrel : 0xFFFFu); reinterpret_cast<T*>(a.skip_val)[sk_base + ei] = r;   // (0xFFFF: unusable, the reader fails over)
                         }

@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
+    const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
     // WIDE (graphs of more than 2^32 - 256 nodes): the lists still hold 32-bit elements -- ids RELATIVE to a per-block base B, 2^31 below the
     // block's first node.  Successors of a web graph lie near their node; a block with an id outside [B, B + 2^32) fails (every id that enters
     // a list is checked where it is made: residuals, skip values, interval ends; copied elements come from checked lists) and stays with
@@ -526,7 +527,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         }
         const uint32_t k1d = (stored && ref == 0 && !direct && !d2) ? 0u : k1;
         // skip entries of the super-row, in node order
-        const uint32_t cntE = (parse && nres >= kSkipMin) ? (nres - 1u) / kSkipEvery : 0u;
+        const uint32_t cntE = (parse && nres >= kSkipMin) ? (nres - 1u) >> kSkipShift : 0u;
         uint32_t efirst;
         {
             const uint32_t eincl = wave_incl_scan32(cntE);
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 // as its longest one, so like goes with like
                 const bool hasres = rparse && nres > 0;
                 const uint32_t ce = hasres ? cntE : 0u;
-                const uint32_t lastc = nres - ce * kSkipEvery;
+                const uint32_t lastc = nres - (ce << kSkipShift);
                 const bool shortt = hasres && lastc <= kShortTask;
                 const uint32_t Tn = hasres ? ce + (shortt ? 0u : 1u) : 0u;            // long tasks of this node
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
@@ -610,8 +611,8 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? ((direct || d2) ? base : rtb) : (gl ? rtb : kInf), nl, 64), t_ef = __shfl(efirst, nl, 64);
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
                         tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
-                        const uint32_t t0 = q * kSkipEvery;
-                        const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;      // the node's entries
+                        const uint32_t t0 = q << kSkipShift;
+                        const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) >> kSkipShift : 0u;      // the node's entries
                         cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
                         trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)((r0 - B) + nl); tpend[u] = t_pend;
                         tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
