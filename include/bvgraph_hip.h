@@ -149,7 +149,8 @@ int bvg_successors_batch(bvg_graph* g, const int64_t* nodes, int64_t count, int3
  * the first scan IS the build; a shard of a multi-GPU scan therefore indexes its own part only, a later scan of other nodes indexes the
  * whole graph); a materialising call (bvg_decode_range) builds it for the whole graph once it covers >= 1/4 of the nodes.  The index is shared by bvg_copy()
  * flyweights: 6 bytes (10 for graphs on the 64-bit successor kernels: more than 2^32 - 256 nodes) per 16 residuals of lists
- * with >= 24 residuals (cf. the offset cache the reference builds at load, BVG:1545-1558).  The same passes VALIDATE the
+ * with >= 16 residuals -- per 8 of lists with >= 8 on graphs with references below 40 arcs per node; the granularity is chosen when
+ * the index is built and travels with it -- (cf. the offset cache the reference builds at load, BVG:1545-1558).  The same passes VALIDATE the
  * blocks: the lean scan kernel then skips the checks a well-formed stream cannot fail, blocks that failed one stay on the
  * checking kernels for good. */
 int bvg_scan(bvg_graph* g, int64_t from, int64_t to, bvg_scan_result* out);
