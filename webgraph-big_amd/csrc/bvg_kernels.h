@@ -26,7 +26,10 @@ inline bool dbg_on() { static const bool on = getenv("BVG_DEBUG") != nullptr; re
 #define BVG_RES_UNROLL 2
 #endif
 constexpr uint32_t kResUnroll = BVG_RES_UNROLL;   // residual segments decoded per lane and pass, interleaved (row kernel)
-constexpr uint32_t kShortTask = 6;   // residual tails this short are dealt after the long tasks of the row
+#ifndef BVG_SHORT_TASK
+#define BVG_SHORT_TASK 6
+#endif
+constexpr uint32_t kShortTask = BVG_SHORT_TASK;   // residual tails this short are dealt after the long tasks of the row
 constexpr uint32_t kSkipMin = BVG_SKIP_MIN, kSkipEvery = BVG_SKIP_EVERY;   // residual skip index granularity (kSkipEvery: a power of two)
 constexpr uint32_t kAccStripes = 2048, kAccStride = 32;   // result stripes (power of two), 256 bytes apart (stripe 0 also carries 16 debug counters)
 constexpr int kRing = 128;           // node-metadata ring (node id mod kRing); supports window sizes <= kMaxWindow
