@@ -278,12 +278,16 @@ const char* bvg_strerror(int status);
 int bvg_abi_version(void);
 
 /* ---- checksum definition (shared with the CPU oracle) ----
- *   kx = splitmix64(x);  k0 = (u32)kx;  k1 = (u32)(kx >> 32) | 1
- *   a  = (u32)y + k0 + (u32)(y >> 32) * 0x9E3779B1        (mod 2^32)
- *   b  = a * 0x85EBCA6B (mod 2^32);  b ^= b >> 15
- *   bvg_arc_mix(x, y) = (u64)b * (u64)k1
+ *   kx = splitmix64(x);  k0 = (u32)kx;  k1 = (u32)(kx >> 32) | 1        (a per-node key, k1 odd)
+ *   bvg_arc_mix(x, y) = k1 * y + k0                                      (mod 2^64)
  * chk = sum of bvg_arc_mix over all arcs, mod 2^64: commutative, so node-range shards reduce with
- * a plain sum (one RCCL all-reduce of {arcs, chk}). */
+ * a plain sum (one RCCL all-reduce of {arcs, chk}).  Linear in y under the node's key: a kernel pays
+ * one 32 x 32 + 64 multiply-add per successor (the reference's SpeedTest.java:127-135 does nothing
+ * with them) and adds d * k0 per node; a single wrong, missing, surplus or misattributed successor
+ * always changes the sum (k1 is odd, keys differ between nodes); two errors inside ONE node that
+ * cancel in the sum of its successors do not -- the materialising parity tests are the primary gate,
+ * this is the scan's self-check.  (Rounds 1-4 used a non-linear mix: six vector instructions per arc,
+ * a quarter of what a decoded successor has to cost.) */
 uint64_t bvg_arc_mix(uint64_t x, uint64_t y);
 
 #ifdef __cplusplus

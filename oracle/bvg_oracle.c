@@ -718,12 +718,7 @@ static inline uint64_t splitmix64(uint64_t x) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
 }
-static inline uint64_t mix_keyed(uint32_t k0, uint32_t k1, uint64_t y) {
-    uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
-    uint32_t a = yl + k0 + yh * 0x9E3779B1u;
-    uint32_t b = a * 0x85EBCA6Bu; b ^= b >> 15;
-    return (uint64_t)b * (uint64_t)k1;
-}
+static inline uint64_t mix_keyed(uint32_t k0, uint32_t k1, uint64_t y) { return (uint64_t)k1 * y + (uint64_t)k0; }   /* mod 2^64 */
 uint64_t bvgo_mix(uint64_t x, uint64_t y) {
     uint64_t kx = splitmix64(x);
     return mix_keyed((uint32_t)kx, (uint32_t)(kx >> 32) | 1u, y);

@@ -159,13 +159,11 @@ __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-__host__ __device__ __forceinline__ uint64_t mix_keyed(uint32_t k0, uint32_t k1, uint64_t y) {
-    uint32_t yl = (uint32_t)y, yh = (uint32_t)(y >> 32);
-    uint32_t a = yl + k0 + yh * 0x9E3779B1u;
-    uint32_t b = a * 0x85EBCA6Bu;
-    b ^= b >> 15;
-    return (uint64_t)b * (uint64_t)k1;
-}
+// one arc: k1 * y + k0 (mod 2^64) -- linear in y under a per-node odd key, so a kernel pays ONE v_mad_u64_u32 per arc (acc = y * k1 + acc) and
+// adds the d * k0 of a node once; a single wrong, missing or surplus successor always changes the sum
+__host__ __device__ __forceinline__ uint64_t mix_keyed(uint32_t k0, uint32_t k1, uint64_t y) { return (uint64_t)k1 * y + (uint64_t)k0; }
+// what a node of outdegree d adds besides k1 * (its successors relative to `nbase`): d * (k1 * nbase + k0)
+__host__ __device__ __forceinline__ uint64_t mix_node_const(uint32_t k0, uint32_t k1, uint64_t nbase, uint64_t d) { return d * ((uint64_t)k1 * nbase + (uint64_t)k0); }
 
 // ---- wave64 helpers ----
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }

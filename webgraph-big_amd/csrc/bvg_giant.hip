@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
     const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
-    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
+    const uint32_t nb_lo = (uint32_t)a.node_base;
     const bool nbz = a.node_base == 0;
 
     for (unsigned i = tid; i < (unsigned)kRing; i += GNT) { nd_base[i] = 0; nd_d[i] = 0; }
@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
         uint32_t k0 = 0, k1 = 0;
         if (rep && !MAT) {
             const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
+            k0 = (uint32_t)kx;
         }
         bool zbad = false;
         // copied elements below v: rank of its lower bound in the referenced list under the mask; an element equal to one of
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
         if (uni32(wg_bad)) { failed = true; GP_WHY(13); break; }
         if (tid == 0) { nd_base[(uint32_t)x & RM] = base; nd_d[(uint32_t)x & RM] = d; }
         pool_used = base + d;
-        if (rep) { blk_arcs += d; blk_nodes += 1; }
+        if (rep) { blk_arcs += d; blk_nodes += 1; if (!MAT && tid == 0) chk += mix_node_const(k0, k1, a.node_base, d); }
         if (MAT && rep) {                                                       // coalesced copy-out
             const uint64_t dst0 = a.batch ? a.cum[bid >> 1] : a.cum[x - a.from];
             for (uint64_t t = tid; t < d; t += GNT) {

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = !GEN && zk >= 2;
     const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
-    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
+    const uint32_t nb_lo = (uint32_t)a.node_base;
     const bool nbz = a.node_base == 0;
     constexpr bool LEAN = !MAT;                              // scan mode: unreferenced lists are not materialised
 
@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         uint32_t k0 = 0, k1 = 0;
         if (rep && !MAT) {
             const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;                   // key with the node_base shift folded in (mix_node)
+            k0 = (uint32_t)kx;
         }
         BVG_T1(9, tq9);
         BVG_T1(5, tq5);
@@ -779,7 +779,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             BVG_T1(10, tqL);
             if (by_tasks) {
                 if (ballot(zbad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
-                if (rep) { blk_arcs += d; blk_nodes += 1; }
+                if (rep) { blk_arcs += d; blk_nodes += 1; if (!MAT) blk_chk += mix_node_const(k0, k1, a.node_base, d); }
             }
         }
         if (!by_tasks) {
@@ -824,7 +824,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (stored) out[j] = m;
                     j++;
                     __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    if (!MAT && rep) chk += m == sentinel<T>() ? mix_keyed(k0 - nb_lo - nb_hi * 0x9E3779B1u, k1, ~0ull) : mix_node<T>(k0, k1, m, nb_lo, nbz);
+                    if (!MAT && rep) chk += m == sentinel<T>() ? (uint64_t)k1 * (~0ull - a.node_base) : mix_node<T>(k0, k1, m, nb_lo, nbz);   // (-1 where the merge ran dry, BVG:1164-1176: the per-node constant adds the base to every arc)
                     if (cneed && c == m) {                                        // MaskedLongIterator.java:81-100
                         rpos++;
                         if (--keep == 0) {
@@ -839,7 +839,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (rsi < nres && rhead == m) { rsi++; rhead = rsi < nres ? rtail[rsi] : sentinel<T>(); }
                 }
             }
-            if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; }
+            if (rep) { blk_arcs += d; blk_chk += chk; blk_nodes += 1; if (!MAT) blk_chk += mix_node_const(k0, k1, a.node_base, d); }
         }
 
         // ------------------------------------------------------------------ materialise: coalesced copy-out

@@ -107,22 +107,11 @@ template <typename T> struct MaskPrefix {
     }
 };
 
-// checksum term of successor m of a node whose key is (kA, k1), kA = k0 + lo(node_base) + hi(node_base) * 0x9E3779B1: the
-// same value as mix_keyed(k0, k1, m + node_base) with the 64-bit add folded into the key (a carry adds the constant once)
-template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t kA, uint32_t k1, T m, uint32_t nbl, bool nbz) {
-    if (sizeof(T) == 8) {
-        const uint64_t m64 = (uint64_t)m; const uint32_t ml = (uint32_t)m64, mh = (uint32_t)(m64 >> 32);
-        uint32_t a_ = ml + kA + mh * 0x9E3779B1u;
-        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
-        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
-        return (uint64_t)b * (uint64_t)k1;
-    } else {
-        const uint32_t ml = (uint32_t)m;
-        uint32_t a_ = ml + kA;
-        if (!nbz && (uint32_t)(ml + nbl) < ml) a_ += 0x9E3779B1u;
-        uint32_t b = a_ * 0x85EBCA6Bu; b ^= b >> 15;
-        return (uint64_t)b * (uint64_t)k1;
-    }
+// checksum term of successor m (an id RELATIVE to the kernel's base: node_base, or the block base of a wide graph) of a node whose key is
+// k1: k1 * m -- one v_mad_u64_u32 for 32-bit lists.  mix_keyed(k0, k1, m + base) = this + (k1 * base + k0), and the bracket is added once per
+// node, times its outdegree (mix_node_const, bvg_device.h).  (kA, nbl, nbz: the old definition's key pieces, unused.)
+template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t /*kA*/, uint32_t k1, T m, uint32_t /*nbl*/, bool /*nbz*/) {
+    return (uint64_t)k1 * (uint64_t)m;
 }
 
 // ordering point for LDS traffic inside ONE wavefront (its lanes run in lock step and its LDS operations complete in

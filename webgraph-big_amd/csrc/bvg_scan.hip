@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     // the 64-bit row kernel.  The checksum takes the base like a node base (mix_node: m + base, carries included).
     const int64_t B = WIDE ? (s > (int64_t)a.wide_half ? s - (int64_t)a.wide_half : 0) : 0;
     const uint64_t nbase = a.node_base + (uint64_t)B;
-    const uint32_t nb_lo = (uint32_t)nbase, nb_hi = (uint32_t)(nbase >> 32);
+    const uint32_t nb_lo = (uint32_t)nbase;
     constexpr bool nbz = NBZ;
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         uint32_t k0 = 0, k1 = 0;
         if (repn && !MAT) {
             const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
+            k0 = (uint32_t)kx;
         }
         // a stored list without reference is emitted from its parked residuals (they play the referenced list): those are summed
         // there; every other residual is summed when it is decoded
@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 }
             }
             BVG_T1(10, tqL);
-            if (rep) { blk_arcs += d; blk_nodes += 1; }
+            if (rep) { blk_arcs += d; blk_nodes += 1; if (!MAT) blk_chk += mix_node_const(k0, k1, nbase, d); }
             if (MAT) {
                 // the lists of the sub-row that were built in the pool leave in coalesced runs (one list after the other: a wave-uniform loop)
                 wave_sync();
