@@ -1,0 +1,39 @@
+"""The product's kernels on the CPU EMULATOR (tests/emu: the .hip sources compiled for the host, every lane of a wavefront a fiber) against the
+oracle.  This container has no GPU: the emulator is where the wavefront code is stepped through, asserted on and run under AddressSanitizer
+before it goes to the GPU box; results must not depend on the order in which the lanes run between two cross-lane operations
+(BVG_EMU_ORDER=rev), or an LDS dependency lacks its wave_sync().  The emulated library is test infrastructure: the product never loads it
+(tests/test_abi.py::test_product_never_touches_the_oracle covers tests/ as a whole: nothing under webgraph-big_amd/ or bench.py names it)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-j4", "-C", EMU, "libbvgraph_emu.so"])
+    return os.path.join(EMU, "libbvgraph_emu.so")
+
+
+def run_case(*args, **env):
+    e = dict(os.environ); e.update({k: str(v) for k, v in env.items()})
+    e.pop("BVG_HIP_LIB", None)
+    out = subprocess.run([sys.executable, os.path.join(EMU, "run_case.py")] + [str(a) for a in args], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return out.stdout
+
+
+@pytest.mark.parametrize("order", ["fwd", "rev"])
+def test_sparse_graph_through_the_emulated_kernels(emu_lib, order):
+    out = run_case(12000, 3, "web", 3, BVG_EMU_ORDER=order)
+    assert "emu case ok" in out and "lean_blocks 0 " in out.splitlines()[0]          # the first scan builds the index on the checking kernels ...
+    assert "lean_blocks 0 " not in out.splitlines()[2]                                # ... and the steady state runs the lean kernel
+
+
+def test_dense_graph_through_the_emulated_kernels(emu_lib):
+    out = run_case(6000, 5, "eu", 3)
+    assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]

@@ -143,7 +143,13 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
                 for (int j = 0; j < cn; j++) {
                     const uint64_t src = __shfl(my_base, j, 64), dst = __shfl(nbase, j, 64), len = __shfl(my_d, j, 64);
                     if (src != dst)
-                        for (uint64_t t = lane; t < len; t += 64) { T v = pool[src + t]; pool[dst + t] = v; }   // (lists lie in node order: a move never lands on one not yet moved)
+                        for (uint64_t t0 = 0; t0 < len; t0 += 64) {                                              // (lists lie in node order: a move never lands on one not yet moved;
+                            const uint64_t t = t0 + lane; T v = 0;                                               //  every element of a step is read before any is written)
+                            if (t < len) v = pool[src + t];
+                            __syncthreads();
+                            if (t < len) pool[dst + t] = v;
+                            __syncthreads();
+                        }
                 }
                 if (livelane) nd_base[(uint64_t)y & RM] = (idx_t)nbase;
                 packed += __shfl(nincl, 63, 64);

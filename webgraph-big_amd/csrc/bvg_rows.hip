@@ -135,7 +135,13 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             for (uint32_t jn = 0; jn < W && jn < 64; jn++) {
                 const uint32_t src = lane_get(my_base, jn), dst = lane_get(nbase, jn), len = lane_get(my_d, jn);
                 if (src != dst)
-                    for (uint32_t t = lane; t < len; t += 64) { const T vv = pool[src + t]; pool[dst + t] = vv; }
+                    for (uint32_t t0 = 0; t0 < len; t0 += 64) {   // (the lists move down over themselves 64 elements at a time: every element of a step is read before any is written)
+                        const uint32_t t = t0 + lane; T vv = 0;
+                        if (t < len) vv = pool[src + t];
+                        wave_sync();
+                        if (t < len) pool[dst + t] = vv;
+                        wave_sync();
+                    }
             }
             if (livelane) nd_base[(uint32_t)y & RM] = nbase;
             pool_used = lane_get(nincl, 63);
