@@ -278,7 +278,8 @@ const char* bvg_strerror(int status);
 int bvg_abi_version(void);
 
 /* ---- checksum definition (shared with the CPU oracle) ----
- *   kx = splitmix64(x);  k0 = (u32)kx;  k1 = (u32)(kx >> 32) | 1        (a per-node key, k1 odd)
+ *   h  = (u32)x * 0x9E3779B1 + (u32)(x >> 32) * 0x85EBCA77;  h ^= h >> 15;  h *= 0x2C1B3C6D;  h ^= h >> 12     (mod 2^32)
+ *   k1 = h | 1;   k0 = h * 0x297A2D39;  k0 ^= k0 >> 15                   (a per-node key, k1 odd; ten 32-bit operations)
  *   bvg_arc_mix(x, y) = k1 * y + k0                                      (mod 2^64)
  * chk = sum of bvg_arc_mix over all arcs, mod 2^64: commutative, so node-range shards reduce with
  * a plain sum (one RCCL all-reduce of {arcs, chk}).  Linear in y under the node's key: a kernel pays

@@ -712,16 +712,16 @@ int bvgo_decode_range(bvgo_graph* g, int64_t from, int64_t to, int32_t* outdeg, 
 /* Scan checksum (definition shared with include/bvgraph_hip.h)                                */
 /* ------------------------------------------------------------------------------------------ */
 
-static inline uint64_t splitmix64(uint64_t x) {
-    uint64_t z = x + 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
+static inline void node_key(uint64_t x, uint32_t* k0, uint32_t* k1) {           /* include/bvgraph_hip.h: the per-node key */
+    uint32_t h = (uint32_t)x * 0x9E3779B1u + (uint32_t)(x >> 32) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    *k1 = h | 1u;
+    uint32_t z = h * 0x297A2D39u; z ^= z >> 15; *k0 = z;
 }
 static inline uint64_t mix_keyed(uint32_t k0, uint32_t k1, uint64_t y) { return (uint64_t)k1 * y + (uint64_t)k0; }   /* mod 2^64 */
 uint64_t bvgo_mix(uint64_t x, uint64_t y) {
-    uint64_t kx = splitmix64(x);
-    return mix_keyed((uint32_t)kx, (uint32_t)(kx >> 32) | 1u, y);
+    uint32_t k0, k1; node_key(x, &k0, &k1);
+    return mix_keyed(k0, k1, y);
 }
 
 int bvgo_scan(bvgo_graph* g, int64_t from, int64_t to, uint64_t node_base, bvgo_scan_result* out) {
@@ -734,8 +734,7 @@ int bvgo_scan(bvgo_graph* g, int64_t from, int64_t to, uint64_t node_base, bvgo_
         if (x < 0) { bvgo_iter_free(it); return (int)x; }
         int64_t d = bvgo_iter_outdegree(it);
         const int64_t* s = bvgo_iter_successors(it);
-        uint64_t kx = splitmix64((uint64_t)x + node_base);
-        uint32_t k0 = (uint32_t)kx, k1 = (uint32_t)(kx >> 32) | 1u;
+        uint32_t k0, k1; node_key((uint64_t)x + node_base, &k0, &k1);
         for (int64_t j = 0; j < d; j++) chk += mix_keyed(k0, k1, (uint64_t)s[j] + node_base);
         arcs += (uint64_t)d; nodes++;
     }

@@ -6,6 +6,7 @@
 // take part.  Lanes of a wavefront that meet at DIFFERENT kinds of operation, or a sweep in which nobody can run, abort with a
 // description: that is divergent control flow around a cross-lane operation, which the kernels here never do on purpose.
 #include <hip/hip_runtime.h>
+#include <execinfo.h>
 #include <sys/mman.h>
 #include <time.h>
 
@@ -42,7 +43,7 @@ emu_switch:
 )");
 
 constexpr size_t kStack = 512 * 1024;
-struct Wave { uint64_t buf[64]; unsigned arrived = 0, live = 0; uint64_t gen = 0; int kind = 0; };
+struct Wave { uint64_t buf[64]; unsigned arrived = 0, live = 0; uint64_t gen = 0; int kind = 0; void* bt[24]; int nbt = 0; unsigned first = 0; };
 struct Fiber { void* sp = nullptr; bool done = false; const uint64_t* wait = nullptr; uint64_t wait_gen = 0; int kind = 0; };
 
 std::vector<Fiber> fibers;
@@ -70,8 +71,11 @@ void trampoline() { (*body)(); fiber_exit(); }
 
 void rendezvous(Wave& w, int kind) {
     Fiber& f = fibers[cur];
-    if (w.arrived == 0) w.kind = kind;
-    else if (w.kind != kind) { fprintf(stderr, "emu: lanes of one wavefront meet at different cross-lane operations (%d vs %d), block %u thread %u\n", w.kind, kind, g_block.x, cur); abort(); }
+    if (w.arrived == 0) { w.kind = kind; w.first = cur; w.nbt = backtrace(w.bt, 24); }
+    else if (w.kind != kind) {
+        void* bt[24]; const int n = backtrace(bt, 24);
+        fprintf(stderr, "emu: thread %u arrived first at:\n", w.first); backtrace_symbols_fd(w.bt, w.nbt, 2);
+        fprintf(stderr, "emu: thread %u is at:\n", cur); backtrace_symbols_fd(bt, n, 2); fprintf(stderr, "emu: lanes of one wavefront meet at different cross-lane operations (%d vs %d), block %u thread %u\n", w.kind, kind, g_block.x, cur); abort(); }
     const uint64_t gen = w.gen;
     if (++w.arrived == w.live) { w.arrived = 0; w.gen++; return; }
     f.wait = &w.gen; f.wait_gen = gen; f.kind = kind;

@@ -8,7 +8,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-os.environ["BVG_HIP_LIB"] = os.path.join(HERE, os.environ.get("BVG_EMU_LIB", "libbvgraph_emu.so"))
+os.environ["BVG_HIP_LIB"] = os.path.join(HERE, os.environ.get("BVG_EMU_LIB", "libbvgraph_emu.so"))     # (an absolute path wins: tests/test_gpu_flat.py runs the same cases on the GPU)
 os.environ.setdefault("BVG_TEST_KNOBS", "1")
 
 import numpy as np  # noqa: E402

@@ -34,6 +34,14 @@ def test_sparse_graph_through_the_emulated_kernels(emu_lib, order):
     assert "lean_blocks 0 " not in out.splitlines()[2]                                # ... and the steady state runs the lean kernel
 
 
+@pytest.mark.parametrize("recs,order,shape,n,seed", [(64, "fwd", "eu", 6000, 5), (64, "rev", "web", 12000, 3), (128, "fwd", "web", 12000, 3), (256, "rev", "eu", 6000, 5), (256, "fwd", "cnr", 40000, 0)])
+def test_flat_scan_kernel_on_the_emulator(emu_lib, recs, order, shape, n, seed):
+    """experimental/bvg_flat.hip (round 5's flat task kernel: per-record state in an LDS table, run items instead of the position loop) against the oracle: every
+    pass structure (64 / 128 / 256 records per super-row), both lane orders, a dense, a sparse and the reference's own graph."""
+    out = run_case(n, seed, shape, 2, BVG_FLAT=1, BVG_FLAT_RECS=recs, BVG_EMU_ORDER=order)
+    assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[1]
+
+
 def test_dense_graph_through_the_emulated_kernels(emu_lib):
     out = run_case(6000, 5, "eu", 3)
     assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]

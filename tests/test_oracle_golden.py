@@ -81,14 +81,12 @@ def test_mix_definition(oracle):
     """The checksum arithmetic written out independently (include/bvgraph_hip.h)."""
     M = (1 << 64) - 1
 
-    def sm(x):
-        z = (x + 0x9E3779B97F4A7C15) & M
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
-        return z ^ (z >> 31)
-
     def mix(x, y):
-        k = sm(x); k0 = k & 0xFFFFFFFF; k1 = (k >> 32) | 1
+        m = 0xFFFFFFFF
+        h = ((x & m) * 0x9E3779B1 + (x >> 32) * 0x85EBCA77) & m
+        h ^= h >> 15; h = (h * 0x2C1B3C6D) & m; h ^= h >> 12
+        k1 = h | 1
+        k0 = (h * 0x297A2D39) & m; k0 ^= k0 >> 15
         return (k1 * y + k0) & M
 
     for x, y in [(0, 0), (1, 2), (325556, 17), (1 << 40, (1 << 35) + 5), (M, M)]:

@@ -752,6 +752,16 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         // The lean scan kernel (bvg_scan.hip) takes the blocks that the index-building pass has validated: scans with 32-bit
         // successors and the default codings, index present.  BVG_SCANK=0 keeps every block on the row kernel (tests, A/B runs).
         bool fast_ok = false; uint32_t lean_waves = 0;
+        // The flat scan kernel (experimental/bvg_flat.hip, round 5: bit-exact, slower -- DESIGN.md) takes what the lean scan kernel takes, for scans (not materialising
+        // calls) of graphs whose ids fit 32 bits, in the experimental build with BVG_FLAT=1; BVG_FLAT_RECS = records per super-row (64 ... 256).
+        const bool flat_on = kExperimental && !materialise && !wide && knob("BVG_FLAT") && atoi(knob("BVG_FLAT")) == 1;
+        uint32_t flat_recs = avg <= 16.0 ? 128u : 64u;
+        if (knob("BVG_FLAT_RECS")) flat_recs = std::min(256u, std::max(64u, (unsigned)atoi(knob("BVG_FLAT_RECS")) & ~63u));
+        const size_t lean_static = flat_on ? flat_table_bytes(flat_recs, sh->p.window_size) : scan_static_lds();
+        auto launch_lean = [&](DecodeArgs& al, uint32_t nb, bool many_waves, hipStream_t st) {
+            if (flat_on) { al.flat_recs = flat_recs; launch_flat_decode(al, nb, many_waves, st); }
+            else launch_scan_decode(al, nb, wide, many_waves, materialise, st);
+        };
         DecodeArgs af = a;
         {
             const Codings& c = a.cod;
@@ -772,7 +782,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 auto stage_of = [&](uint64_t w) -> uint32_t {
                     return knob("BVG_SCAN_STAGE") ? (uint32_t)std::min(2048, std::max(128, atoi(knob("BVG_SCAN_STAGE")) & ~3)) : std::min<uint32_t>(a.lds_stage_words, w >= 16 ? 384 : 512);
                 };
-                auto foot = [&](uint64_t pe, uint64_t w) { return (pe * 4 + scan_static_lds() + 64 + (uint64_t)stage_of(w) * 4 + scrw * 4 + 127) & ~127ull; };
+                auto foot = [&](uint64_t pe, uint64_t w) { return (pe * 4 + lean_static + 64 + (uint64_t)stage_of(w) * 4 + scrw * 4 + 127) & ~127ull; };
                 const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 20.0;   // window lists + a sub-row's stored lists and parked residuals
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
@@ -788,14 +798,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 if (knob("BVG_SCAN_POOL")) pool = std::min<uint64_t>(std::max<uint64_t>(strtoull(knob("BVG_SCAN_POOL"), nullptr, 10), 512), 12288);
                 af.lds_pool_elems = (uint32_t)pool; af.lds_scr_elems = (uint32_t)scrw;
                 af.lds_stage_words = stagew;
-                if (dbg_on()) fprintf(stderr, "[bvg] scan kernel: pool %u + scratch %u elements, window %u dwords, %llu wavefronts per CU\n", af.lds_pool_elems, af.lds_scr_elems, af.lds_stage_words, (unsigned long long)waves);
+                if (dbg_on()) fprintf(stderr, "[bvg] %s: pool %u + scratch %u elements, window %u dwords, %llu wavefronts per CU\n", flat_on ? "flat kernel" : "scan kernel", af.lds_pool_elems, af.lds_scr_elems, af.lds_stage_words, (unsigned long long)waves);
             }
         }
         if (predict) {
             // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
             bvg_graph::Pred& pd = g->pred;
             const uint32_t pool0 = a.lds_pool_elems;
-            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u) | (fast_ok ? 32u : 0u) | (fast_ok ? (af.lds_pool_elems << 8) : 0u);
+            const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u) | (fast_ok ? 32u : 0u) | (fast_ok && flat_on ? 64u : 0u) | (fast_ok ? (af.lds_pool_elems << 8) : 0u);
             const uint64_t cap0 = flow ? 6144 : pool0;                          // the flow kernel keeps long lists in its scratch area
             const uint64_t sgen = (a.skip_first && skx) ? skx->gen : 0;         // the snapshot the marks / entry layouts come from: another one, another split
             const bool rekey = pd.plan_version != pl.version || pd.skip_gen != sgen || pd.lo != lo || pd.n != nblocks || pd.pool0 != pool0 || pd.mode != pmode || !pd.d_lists;
@@ -886,7 +896,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
             auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
-            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), materialise, g->stream); launches++; alone(g->stream); }
+            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_lean(a7, pd.count[7], lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), g->stream); launches++; alone(g->stream); }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 if (ag.skip_mode == 3) ag.skip_mode = 2;                              // (the giant kernel fills its own entries, in its own format, while it validates)
@@ -926,11 +936,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 ac.lds_pool_elems = lclasses[c - 1]; ac.lds_scr_elems = cscr[c - 1]; ac.lds_stage_words = cstage[c - 1];
                 if (knob("BVG_CLASS_STAGE")) { unsigned v[4] = {1024, 1024, 1024, 1024}; sscanf(knob("BVG_CLASS_STAGE"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_stage_words = std::min(2048u, std::max(128u, v[c - 1] & ~3u)); }   // experiments: the classes' LDS geometry
                 if (knob("BVG_CLASS_SCR")) { unsigned v[4] = {1024, 1024, 2048, 3072}; sscanf(knob("BVG_CLASS_SCR"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_scr_elems = std::min(8192u, std::max(128u, v[c - 1])); }
-                launch_scan_decode(ac, pd.count[7 + c], wide, false, materialise, side_of(c)); alone(side_of(c));
+                launch_lean(ac, pd.count[7 + c], false, side_of(c)); alone(side_of(c));
                 launches++;
             }
             if (t0_waits) HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[0], 0));
-            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_scan_decode(a7, pd.count[7], wide, lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), materialise, g->stream); launches++; alone(g->stream); }
+            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_lean(a7, pd.count[7], lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
@@ -1060,6 +1070,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     HIPCHK(hipStreamSynchronize(g->stream));
     if (a.dbg & 64u) fprintf(stderr, "[bvg] counters: position steps %llu, position passes %llu, extras passes %llu, rows %llu, position tasks %llu, leaf steps %llu, leaf passes %llu\n", acc[4], acc[5], acc[8], acc[6], acc[7], acc[22], acc[23]);
     if ((a.dbg & 64u) && lean_blocks) fprintf(stderr, "[bvg] scan kernel rows: %llu super-rows, %llu sub-rows, %llu nodes in them\n", acc[5], acc[6], acc[7]);
+    if ((a.dbg & 64u) && lean_blocks && knob("BVG_FLAT_PROF"))          // `make flatprof` (-DBVG_FLAT_PROF): the flat kernel's section cycles and work counts (bvg_flat.hip)
+        fprintf(stderr, "[bvg] flat kernel wave-cycles (M): super-row set-up %.0f, headers %.0f, peek/marks %.0f, sizing+stages %.0f, residual set-up %.0f, residual steps %.0f, Z1 %.0f, item set-up %.0f, chunks %.0f, compaction %.0f | "
+                "super-rows %llu sub-rows %llu records %llu | residual passes %llu steps %llu | Z1 passes %llu | item passes %llu chunk passes %llu chunk steps %llu\n",
+                acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6, acc[14] / 1e6, acc[15] / 1e6, acc[16] / 1e6, acc[17] / 1e6, acc[18] / 1e6,
+                acc[19], acc[20], acc[21], acc[22], acc[23], acc[24], acc[25], acc[26], acc[27]);
 #ifndef BVG_PROF_WORK
     if ((a.dbg & 64u) && acc[14]) {                         // only the -DBVG_PROF build fills these
         fprintf(stderr, "[bvg] wave-cycles (M): phase1 %.0f, row prep %.0f, level prep %.0f, task set-up %.0f, seeks %.0f, merge loop %.0f\n", acc[14] / 1e6, acc[9] / 1e6, acc[10] / 1e6, acc[11] / 1e6, acc[12] / 1e6, acc[13] / 1e6);
@@ -2123,8 +2138,8 @@ int bvg_store(const bvg_params* p, int64_t nodes, const uint64_t* adj_off, const
 void bvg_free(void* p) { free(p); }
 
 uint64_t bvg_arc_mix(uint64_t x, uint64_t y) {
-    uint64_t kx = splitmix64(x);
-    return mix_keyed((uint32_t)kx, (uint32_t)(kx >> 32) | 1u, y);
+    uint32_t k0, k1; node_key(x, k0, k1);
+    return mix_keyed(k0, k1, y);
 }
 
 const char* bvg_strerror(int status) {

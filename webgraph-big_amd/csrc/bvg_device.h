@@ -161,6 +161,14 @@ __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 // one arc: k1 * y + k0 (mod 2^64) -- linear in y under a per-node odd key, so a kernel pays ONE v_mad_u64_u32 per arc (acc = y * k1 + acc) and
 // adds the d * k0 of a node once; a single wrong, missing or surplus successor always changes the sum
+// the per-node key of the scan checksum (include/bvgraph_hip.h): a multiply / xor-shift hash of the 64-bit node id -- ten 32-bit vector
+// instructions, so a kernel recomputes k1 wherever a task needs it instead of carrying it around (splitmix64, rounds 1-4, is ~25)
+__host__ __device__ __forceinline__ void node_key(uint64_t x, uint32_t& k0, uint32_t& k1) {
+    uint32_t h = (uint32_t)x * 0x9E3779B1u + (uint32_t)(x >> 32) * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    k1 = h | 1u;
+    k0 = h * 0x297A2D39u; k0 ^= k0 >> 15;
+}
 __host__ __device__ __forceinline__ uint64_t mix_keyed(uint32_t k0, uint32_t k1, uint64_t y) { return (uint64_t)k1 * y + (uint64_t)k0; }
 // what a node of outdegree d adds besides k1 * (its successors relative to `nbase`): d * (k1 * nbase + k0)
 __host__ __device__ __forceinline__ uint64_t mix_node_const(uint32_t k0, uint32_t k1, uint64_t nbase, uint64_t d) { return d * ((uint64_t)k1 * nbase + (uint64_t)k0); }

@@ -625,8 +625,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
         const bool rep = x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
         if (rep && !MAT) {
-            const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx;
+            node_key((uint64_t)x + a.node_base, k0, k1);
         }
         bool zbad = false;
         // copied elements below v: rank of its lower bound in the referenced list under the mask; an element equal to one of

@@ -104,6 +104,7 @@ struct DecodeArgs {
                                         // kernel (two slots per entry: 32-bit offsets); a kernel uses only entries of its own format
     uint32_t skip_mode;
     uint32_t xcds;                      // XCDs the work order is laid out for (8 on MI355X; 1 = plain order): xcd_order(), bvg_rows_common.h
+    uint32_t flat_recs;                 // flat scan kernel (experimental/bvg_flat.hip): records per super-row (a multiple of 64: 64 on dense graphs, up to 256 on sparse ones)
 };
 
 void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, bool slow, hipStream_t s);
@@ -129,6 +130,10 @@ void launch_stream_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool
 size_t flow_scratch_bytes_per_wave(int window);
 size_t flow_lds_bytes(uint32_t ring_cap);
 void launch_flow_scan(const DecodeArgs& a, uint32_t nblocks, uint32_t waves, void* scratch, uint32_t ring_cap, hipStream_t s);
+// the flat scan kernel (experimental/bvg_flat.hip, round 5): scan_kernel's blocks with per-record state in an LDS table and every pass a flat task list over
+// 64-256 records; bit-exact, slower: BVG_FLAT=1 selects it in the experimental build
+void launch_flat_decode(const DecodeArgs& a, uint32_t nblocks, bool many_waves, hipStream_t s);
+size_t flat_table_bytes(uint32_t recs, int window);
 #else
 constexpr bool kExperimental = false;
 inline void launch_rows_wg_decode(const DecodeArgs&, uint32_t, int, hipStream_t) {}
@@ -136,6 +141,8 @@ inline size_t rows_wg_static_lds(int) { return 0; }
 inline size_t flow_scratch_bytes_per_wave(int) { return 0; }
 inline size_t flow_lds_bytes(uint32_t) { return 0; }
 inline void launch_flow_scan(const DecodeArgs&, uint32_t, uint32_t, void*, uint32_t, hipStream_t) {}
+inline void launch_flat_decode(const DecodeArgs&, uint32_t, bool, hipStream_t) {}
+inline size_t flat_table_bytes(uint32_t, int) { return 0; }
 #endif
 
 // tier 2a (bvg_giant.hip): blocks with lists / records too large for LDS, one 256-thread workgroup per block, work areas as for the

@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) decode_kernel(DecodeArgs a) {
         // ------------------------------------------------------------------ phase 2: data-flow emission
         const bool rep = act && x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
-        if (rep && !MAT) { uint64_t kx = splitmix64((uint64_t)x + a.node_base); k0 = (uint32_t)kx; k1 = (uint32_t)(kx >> 32) | 1u; }
+        if (rep && !MAT) node_key((uint64_t)x + a.node_base, k0, k1);
         T* const out = pool + base;
         const T* rl = pool; uint32_t rlen = 0, rpos = 0, keep = 0, bi = 0; int rlane = -1;
         if (act && ref > 0) {

@@ -496,8 +496,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
         const bool rep = act && x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
         if (rep && !MAT) {
-            const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx;
+            node_key((uint64_t)x + a.node_base, k0, k1);
         }
         BVG_T1(9, tq9);
         BVG_T1(5, tq5);

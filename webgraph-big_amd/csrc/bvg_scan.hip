@@ -507,8 +507,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         // checksum key of the node (mix_node): a node outside [from, to) sums nothing (k1 = 0)
         uint32_t k0 = 0, k1 = 0;
         if (repn && !MAT) {
-            const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx;
+            node_key((uint64_t)x + a.node_base, k0, k1);
         }
         // a stored list without reference is emitted from its parked residuals (they play the referenced list): those are summed
         // there; every other residual is summed when it is decoded
