@@ -52,8 +52,20 @@ SHAPES = {
     "cnr": ("golden", {}, {}, 0, "cnr-2000 (LAW; the reference's fixture, W=7 maxRef=3 minInterval=3 zeta3) tiled on the device"),
 }
 GOLDEN = os.path.join(ROOT, "tests", "golden", "cnr-2000")
-KERNEL_REV = "r04"      # profiles/traffic.json entries measured on other kernels are not quoted
+KERNEL_REV = "r05"      # profiles/traffic.json entries measured on other kernels are not quoted ...
 VALU_PEAK_WINSTR_PER_S = 1024 / 1.83e-9   # 256 CUs x 4 SIMDs, one wave-instruction per 1.83 ns each (profiles/r03_valu_rates.txt, measured on the card)
+VALU_PEAK_FULL_RATE = 1024 / 1.07e-9      # ... per 1.07 ns for the full-rate operations (v_add / sub / and / or / xor / lshr / mov: profiles/r04_valu_rates2.txt)
+
+
+def kernel_source_id():
+    """... and an entry counts only for the kernel SOURCES it was measured on: a hash over webgraph-big_amd/csrc (what libbvgraph_hip.so is built from).  A PMC
+    pass on file for an earlier tree never decorates a later kernel: `traffic` and `roofline_valu` are null until the pass is repeated (profiles/r05/pmc.sh + record.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "webgraph-big_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 VALU_FLOOR_PER_ARC = 30.0 / 64.0          # ~30 lane-operations of decode + checksum per arc (DESIGN.md 7c) on 64 lanes
 # the 8 bases of the eu15 mosaic: (seed, eu_like overrides).  Mean outdegree ~86 over the cycle (eu-2015: 85.7); the tiles differ in
 # density, in how much they copy and in how long their copy blocks, intervals and residual lists are.
@@ -309,13 +321,18 @@ def main():
                        "nodes": n_graph * (world if scaling == "weak" else 1), "arcs": tot_arcs, "graph_bytes": total_gbytes,
                        "nodes_per_gpu": hi - lo, "arcs_per_gpu": int(r["arcs"]), "graph_bytes_per_gpu": gbytes,
                        "bits_per_link": 8.0 * gbytes / max(int(r["arcs"]), 1), "tiles": copies * max(len(sts), 1), "distinct_tiles": max(len(sts), 1), "base_nodes": args.base_nodes,
+                       "structure": structure_of(sts),
                        "sharding": ("%d arc-balanced node-range shard(s) of one graph, a replica per GPU" % world if scaling == "strong" else "%d graph(s), one per GPU, ids shifted" % world)
-                                   + "; RCCL all-reduce of {arcs,chk} only"},
+                                   + "; RCCL all-reduce of {arcs,chk} only",
+                       "collective": {"backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if dist is not None else None,
+                                      "world_size": (dist.get_world_size() if dist is not None else 1), "one_device": bool(args.one_device)}},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": None, "traffic_source": None,
                          "kernel": ("bvg::scan_kernel (tier 0 and, with larger pools, the big-LDS classes: %d of %d blocks of the last scan)" % (r["lean_blocks"], r["lean_blocks"] + r["slow_blocks"]) if r.get("lean_blocks") else "bvg::rows_kernel<%s,scan,tasks> (tier 0 and, with larger pools, the big-LDS classes)" % ("u32" if n_graph <= 0xFFFFFF00 else "u64"))
                                    + ", rows_kernel / giant_kernel / decode_kernel<slow> for the other blocks and reduce_acc_kernel launched beside it: hipEvent time of one scan on the handle's stream", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": gbytes, "index_bytes_per_launch": r["index_bytes"]},
+                         "algorithmic_bytes_per_launch": gbytes, "index_bytes_per_launch": r["index_bytes"],
+                         # the bytes the kernels really have to read: the stream AND the index beside it (packed offsets, block plan, skip entries)
+                         "frac_with_index": (gbytes + r["index_bytes"]) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "checksum": "%016x" % tot_chk, "arcs": tot_arcs, "slow_blocks": r["slow_blocks"],
             "index": {"skip_entries_rank0": int(r["index_entries"]), "skip_entries_all_ranks": idx_all, "lean_blocks_rank0": int(r["lean_blocks"]), "lean_blocks_all_ranks": lean_all},
             "index_build_s": max(first_scan_s - steady_s, 0.0), "hbm_resident_bytes": int(resident),
@@ -340,10 +357,11 @@ def main():
                 # PMC pass on file for this very workload and kernel revision x the arcs/s measured NOW, against the issue peak measured on the card.
                 ach = t["valu_per_arc"] * edges_per_s / max(world, 1)
                 out["roofline_valu"] = {"bound": "valu-issue", "achieved": ach, "peak": VALU_PEAK_WINSTR_PER_S, "unit": "wave-instr/s", "frac": ach / VALU_PEAK_WINSTR_PER_S,
+                                        "frac_full_rate": ach / VALU_PEAK_FULL_RATE,
                                         "valu_per_arc": t["valu_per_arc"], "salu_per_arc": t.get("salu_per_arc"), "lds_per_arc": t.get("lds_per_arc"), "active_lanes": t.get("active_lanes"),
                                         "floor_valu_per_arc": VALU_FLOOR_PER_ARC, "x_floor": t["valu_per_arc"] / VALU_FLOOR_PER_ARC,
                                         "edges_per_s_at_floor": VALU_PEAK_WINSTR_PER_S / VALU_FLOOR_PER_ARC, "source": t.get("valu_source"),
-                                        "peak_full_rate_ops": 1024 / 1.07e-9,
+                                        "peak_full_rate_ops": VALU_PEAK_FULL_RATE,
                                         "note": "peak = 1 024 SIMDs / 1.83 ns, the issue time of the half-rate instructions (shifts left, three-operand integer forms, multiplies, compares, selects: "
                                                 "most of this kernel); v_add/sub/and/or/xor/lshr/mov issue in 1.07 ns (profiles/r04_valu_rates2.txt), so a mix rich in those can pass frac 1"}
         if not args.no_cpu_baseline and world == 1:                      # (rank 0 at N = 1 only: at N > 1 the other ranks would wait for it)
@@ -377,8 +395,9 @@ def measured_pmc(shape, tiles, base_nodes, world, scaling):
         rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except Exception:
         return None
+    src = kernel_source_id()
     for e in rec.get("runs", []):
-        if e.get("rev") != KERNEL_REV:
+        if e.get("rev") != KERNEL_REV or e.get("src_id") != src:
             continue
         if (e.get("shape"), e.get("tiles"), e.get("base_nodes"), e.get("n_gpus", 1), e.get("scaling", "weak")) == (shape, tiles, base_nodes, world, scaling if world > 1 else e.get("scaling", "weak")):
             return e
@@ -457,6 +476,45 @@ def effective_cpus(threads):
     return n
 
 
+def structure_of(sts):
+    """How the workload's lists are built, in the reference's own terms (avgref / avgdist as BVGraph.store writes them, BVG:2280-2281,2500-2501; arc provenance as in SURVEY
+    Appendix B), next to the same figures of the one real LAW graph in the tree -- so that a reader can see how far the stand-in is from a crawl."""
+    cnr = {"avgref": 1.38, "avgdist": 1.74, "copied": 0.663, "intervals": 0.113, "residuals": 0.225, "arcs_per_node": 9.88, "bits_per_link": 3.56,
+           "source": "tests/golden/cnr-2000.properties (the reference's fixture) and SURVEY.md Appendix B"}
+    tot = {k: 0 for k in ("arcs", "copied", "intervalised", "residual", "tot_ref", "tot_dist")}
+    nodes = 0
+    for st in sts or []:
+        s = getattr(st, "stats", None)
+        if not s or "copied" not in s:                                    # (a graph from disk: only what its .properties say)
+            return {"cnr-2000": cnr}
+        for k in tot:
+            tot[k] += int(s.get(k, 0))
+        nodes += int(st.params.nodes)
+    if not nodes or not tot["arcs"]:
+        return {"cnr-2000": cnr}
+    a = float(tot["arcs"])
+    return {"avgref": tot["tot_ref"] / nodes, "avgdist": tot["tot_dist"] / nodes, "copied": tot["copied"] / a, "intervals": tot["intervalised"] / a, "residuals": tot["residual"] / a,
+            "arcs_per_node": a / nodes, "cnr-2000": cnr}
+
+
+def reference_java(basename):
+    """The reference itself, timed beside the GPU when the box can run it: `java -cp $BVG_REFERENCE_CP it.unimi.dsi.big.webgraph.test.SpeedTest
+    <basename>` (test/SpeedTest.java:117-146: single-threaded sequential scan, 3 warm-up + 10 timed) needs a JVM, the reference's classes with their dsiutils / fastutil /
+    sux4j jars on BVG_REFERENCE_CP, and a graph on disk.  None of them exists in this image (no java, no jars, no network): the probe says so instead of staying silent."""
+    import shutil
+    import subprocess
+    java, cp = shutil.which("java"), os.environ.get("BVG_REFERENCE_CP")
+    if not java:
+        return "not available: no `java` on PATH (run-time probe); the reported baseline is the C port of the same decode path"
+    if not cp or not basename:
+        return "not run: a JVM exists (%s) but %s" % (java, "BVG_REFERENCE_CP does not name the reference's classes and jars" if not cp else "the workload is synthetic (SpeedTest takes a basename on disk)")
+    try:
+        r = subprocess.run([java, "-server", "-cp", cp, "it.unimi.dsi.big.webgraph.test.SpeedTest", basename], capture_output=True, text=True, timeout=1800)
+        return {"cmd": "java -server -cp $BVG_REFERENCE_CP it.unimi.dsi.big.webgraph.test.SpeedTest " + basename, "rc": r.returncode, "stdout_tail": r.stdout[-1500:], "stderr_tail": r.stderr[-500:]}
+    except Exception as ex:                                               # a broken class path must not take the bench line with it
+        return "failed to run: %r" % (ex,)
+
+
 def cpu_baseline(sts, bases_gpu, basename, threads, gib):
     """The CPU oracle -- an unoptimised C restatement (PORT) of the reference's decode path, per-node mallocs and all; no JVM exists
     here, so not the reference itself and no statement about the Java's speed -- timed on this box's host cores over a `gib`-GiB prefix
@@ -497,6 +555,7 @@ def cpu_baseline(sts, bases_gpu, basename, threads, gib):
     sample = max(1, min(n, int(n * min(1.0, 5.0 / max(tm * threads, 1e-3)))))
     t0 = time.perf_counter(); r2 = og.scan(0, sample, threads=1); t1 = time.perf_counter() - t0
     return {"value": r1["arcs"] / tm, "unit": "edges/s", "cores": threads, "threads": threads, "value_first_scan": r1["arcs"] / first, "kind": "port",
+            "reference_java": reference_java(basename),
             "sample": what + "%d nodes, %d arcs, %.2f GiB of .graph), mean of %d scans with %d threads over contiguous node ranges; 1 thread on the first %d nodes: %.3g edges/s; the port is an unoptimised restatement (a malloc per node), not the reference's Java"
                       % (n, r1["arcs"], gbytes / (1 << 30), reps, threads, sample, r2["arcs"] / max(t1, 1e-9)),
             "value_1thread": r2["arcs"] / max(t1, 1e-9), "gpu_matches_oracle": gate}
