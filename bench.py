@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--no-index-leg", action="store_true", help="skip the three index-less scans behind the timed region (value_no_index)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on a one-GPU box)")
     ap.add_argument("--echo-ranks", action="store_true", help="plumbing test: every rank prints 'rank r of w' and exits before touching the GPU")
+    ap.add_argument("--verify-whole", action="store_true", help="strong scaling: rank 0 also scans the whole graph in one piece (untimed) and compares it with the reduced {arcs, chk}")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
@@ -168,16 +169,30 @@ def main():
                     return [T.synth_store(args.base_nodes, seed=sd, params=params, synth=T.eu_like(**kw), threads=nthreads) for sd, kw in MIX]
                 return [T.synth_store(args.base_nodes, seed=0, params=params, synth=T.eu_like(**skw) if kind == "eu" else T.web_like(**skw), threads=nthreads)]
             if dist is not None and world > 1:
-                share = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bvg_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid()))
-                if rank == 0:
-                    sts = generate(max(1, min(ncpu, 64)))                 # the other ranks wait at the barrier: rank 0 may use every core
-                    save_stores(share, sts)
-                dist.barrier()
-                if rank != 0:
-                    sts = load_stores(share)
-                dist.barrier()
-                if rank == 0:
-                    remove_stores(share)
+                # The bases are generated once PER NODE, by its local rank 0 (same seeds: identical on every node), and handed to the node's other ranks through a
+                # private directory (mode 0700, a random name that rank 0 broadcasts: nothing predictable in a world-writable place), removed whatever happens.
+                import secrets
+                tok = [secrets.token_hex(8) if rank == 0 else None]
+                dist.broadcast_object_list(tok, src=0)
+                sdir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bvg_bench_%s" % tok[0])
+                share = os.path.join(sdir, "b")
+                leader = int(os.environ.get("LOCAL_RANK", rank)) == 0
+                try:
+                    if leader:
+                        os.mkdir(sdir, 0o700)
+                        sts = generate(max(1, min(ncpu, 64)))             # the node's other ranks wait at the barrier: its leader may use every core
+                        save_stores(share, sts)
+                    dist.barrier()
+                    if not leader:
+                        sts = load_stores(share)
+                    dist.barrier()
+                finally:
+                    if leader:
+                        remove_stores(share)
+                        try:
+                            os.rmdir(sdir)
+                        except OSError:
+                            pass
             else:
                 sts = generate(threads)
         gen_s = time.time() - t0
@@ -255,6 +270,10 @@ def main():
                 rg = g.scan(a0, a0 + span)
                 assert (rg["arcs"], rg["chk"]) == (ro["arcs"], ro["chk"]), "GPU scan of nodes [%d, %d) disagrees with the CPU oracle" % (a0, a0 + span)
             del og
+    if scaling == "strong" and world > 1 and args.verify_whole and rank == 0:
+        # optional (it makes rank 0 index and scan the whole replica, which the timed configuration never does): the reduced pair against the ONE-PIECE scan
+        rw = g.scan(0, n_graph)
+        assert (rw["arcs"], rw["chk"]) == (tot_arcs, tot_chk), "the shards' reduced {arcs, chk} differ from the one-piece scan"
     if scaling == "strong" and world > 1 and not args.no_verify:
         # Every rank gates ITS OWN shard (no rank scans -- or indexes -- the whole replica): the tiles above against the CPU oracle, and
         # the shard as a whole against the sum of its pieces scanned one by one through the same handle (additivity: the checksum is a

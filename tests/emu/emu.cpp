@@ -159,8 +159,12 @@ uint64_t clock() { static uint64_t c = 0; return c += 16; }
 
 }  // namespace emu
 
+// tests: the next `n` device allocations fail (hipErrorOutOfMemory), as on a card whose memory another handle holds
+static int g_fail_mallocs = 0;
+extern "C" void emu_fail_next_mallocs(int n) { g_fail_mallocs = n; }
 hipError_t emu_malloc(void** p, size_t n) {
     *p = nullptr;
+    if (g_fail_mallocs > 0) { g_fail_mallocs--; return hipErrorOutOfMemory; }
     if (posix_memalign(p, 256, std::max<size_t>(n, 1)) != 0) { *p = nullptr; return hipErrorOutOfMemory; }
     memset(*p, 0xCD, n);                        // device memory is not zeroed
     return hipSuccess;

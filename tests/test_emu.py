@@ -42,6 +42,14 @@ def test_flat_scan_kernel_on_the_emulator(emu_lib, recs, order, shape, n, seed):
     assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[1]
 
 
+def test_a_failed_allocation_during_the_index_build_is_transient(emu_lib):
+    """bvg_api.hip give_up(): an out-of-memory failure of the index build is remembered (no counting pass per scan), announced once, and retried every 8th scan."""
+    e = dict(os.environ); e.pop("BVG_HIP_LIB", None); e.pop("BVG_DEBUG", None)
+    out = subprocess.run([sys.executable, os.path.join(EMU, "run_oom.py")], env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "oom case ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stderr.count("warning: the residual skip index") == 1 and "out of device memory" in out.stderr, out.stderr[-2000:]
+
+
 def test_dense_graph_through_the_emulated_kernels(emu_lib):
     out = run_case(6000, 5, "eu", 3)
     assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]

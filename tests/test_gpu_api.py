@@ -608,6 +608,32 @@ def test_offsets_are_derived_by_the_chunk_parallel_walk(W, tools, capfd, monkeyp
         W.BVGraph.from_memory(st.params, cut, None)
 
 
+def test_offsets_are_derived_across_a_record_of_hundreds_of_chunks(W, tools, capfd, monkeypatch):
+    """A hub with millions of residuals (what bvg_giant.hip exists for) spans hundreds of 4 KiB chunks of the bare stream; inside it the parallel walk of
+    csrc/bvg_derive.hip settles exactly one chunk per round -- the crawl, not a stall: the derivation must finish on the parallel walk (round 4 gave up after
+    256 such rounds and restarted the one-wavefront walk from bit 0) and reproduce the encoder's offsets."""
+    monkeypatch.setenv("BVG_DEBUG", "1")
+    rng = np.random.default_rng(11)
+    n = 1 << 25
+    hub = np.unique(rng.integers(0, n, 3300000)).astype(np.int64)
+    few = np.sort(rng.choice(n, 20000, replace=False))                          # some ordinary records around it
+    deg = np.zeros(n, dtype=np.int64); deg[few] = 3; deg[n // 3] = len(hub)
+    off = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64)
+    succ = np.empty(int(off[-1]), dtype=np.int64)
+    for x in few:
+        if x != n // 3:
+            succ[int(off[x]):int(off[x + 1])] = np.minimum(x + np.array([1, 5, 9]), n - 1)
+    succ[int(off[n // 3]):int(off[n // 3 + 1])] = hub
+    st = tools.store((off, succ), W.default_params(), threads=8)
+    assert int(np.diff(st.offsets.astype(np.int64)).max()) > 520 * 32768         # the hub's record: more chunks than round 4's give-up rule allowed rounds
+    capfd.readouterr()
+    g = W.BVGraph.from_memory(st.params, st.graph, None)
+    err = capfd.readouterr().err
+    assert "parallel walk ok" in err and "giving up" not in err, err[-2000:]
+    assert np.array_equal(g.offsets(), st.offsets)
+    g.close()
+
+
 def _cpu_transpose(n, deg, succ):
     src = np.repeat(np.arange(n, dtype=np.int64), deg)
     order = np.argsort(succ, kind="stable")                       # stable: sources stay increasing inside every target

@@ -63,8 +63,17 @@ struct SkipIndex {
     uint64_t total = 0; uint64_t* d_first = nullptr; uint16_t* d_bit = nullptr; void* d_val = nullptr; uint8_t* d_fmt = nullptr;
     bool wide = false;                        // entries hold 64-bit values (built by the 64-bit kernels); a handle running the other width ignores the index
     uint32_t skip_min = kSkipMin, skip_shift = 4;   // granularity: lists of >= skip_min residuals hold one entry per 2^skip_shift residuals (skip_granularity() when it is built)
-    bool failed = false;                      // the build of [blk_lo, blk_hi) failed (out of memory, malformed stream): no arrays; scans of those blocks run index-less and
-                                              // do NOT try again on their own (only bvg_build_index does)
+    bool failed = false;                      // the build of [blk_lo, blk_hi) failed: no arrays; scans of those blocks run index-less.  WHY it failed decides what happens next:
+    enum { kStream = 1, kResources = 2 };     //   a stream the checking kernels refuse stays refused (only bvg_build_index tries again); running out of memory (or any other HIP
+    int fail_cause = 0;                       //   error) is transient: the scans try again every kRetryEvery-th time.  Several failed ranges (two shards that alternate) are kept
+    std::vector<std::pair<uint32_t, uint32_t>> failed_ranges;   // side by side, so that neither pays its counting pass again because of the other.
+    mutable std::atomic<uint32_t> backoff{0}; // scans left before the next automatic attempt (a failed snapshot with kResources; a good partial one whose whole-graph rebuild failed)
+    static constexpr uint32_t kRetryEvery = 8;
+    bool covers(uint32_t lo, uint32_t hi) const {
+        if (!failed) return blk_lo <= lo && hi <= blk_hi;
+        for (const auto& r : failed_ranges) if (r.first <= lo && hi <= r.second) return true;
+        return false;
+    }
     uint64_t gen = 0;                         // identity of this snapshot: what a handle learned about blocks (tier lists, lean / row split) holds for ONE snapshot only
     std::vector<uint64_t> h_first;            // nblk + 1 entry indices (host copy: index_bytes of a range)
     std::vector<uint8_t> h_fmt;               // host copy of d_fmt: 1 = validated by the row kernel (the lean scan kernel may take the block)
@@ -425,7 +434,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     Plan& pl = *plp;
     {
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&pl.skip);
-        if (cur && !(cur->failed && retry_failed) && cur->blk_lo <= blo && bhi <= cur->blk_hi) return 0;   // another thread built it meanwhile (or failed to: not tried again here)
+        if (cur && !(cur->failed && retry_failed) && cur->covers(blo, bhi)) return 0;   // another thread built it meanwhile (or failed to: not tried again here)
         if (cur && !cur->failed) { blo = 0; bhi = pl.nblk; first_scan = nullptr; }   // a second range: index the whole graph once and for all (the scan's own range is a part of it: it scans afterwards)
     }
     const uint32_t nblk = pl.nblk;
@@ -438,37 +447,44 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     auto publish = [&]() { std::atomic_store(&pl.skip, ix); return 0; };
     // no index: the scans run without one.  The failure is PUBLISHED (an empty snapshot of the same block range, unless a good index of
     // other blocks exists already), so that later scans of these blocks do not pay the counting pass again and again; bvg_build_index() retries.
-    auto give_up = [&]() {
+    auto give_up = [&](int cause) {
         (void)hipGetLastError();
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&pl.skip);
         if (!cur || cur->failed) {
             std::shared_ptr<SkipIndex> fx = std::make_shared<SkipIndex>();
             fx->device = sh->device; fx->blk_lo = blo; fx->blk_hi = bhi; fx->wide = build_wide; fx->failed = true; fx->gen = next_plan_version();
+            fx->fail_cause = cause; fx->backoff.store(SkipIndex::kRetryEvery);
+            if (cur) for (const auto& r : cur->failed_ranges) if (!(blo <= r.first && r.second <= bhi) && fx->failed_ranges.size() < 64) fx->failed_ranges.push_back(r);   // the ranges that failed before stay failed
+            fx->failed_ranges.emplace_back(blo, bhi);
             std::atomic_store(&pl.skip, fx);
-        }
-        if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: build of blocks [%u, %u) failed; scanning without it\n", blo, bhi);
+        } else cur->backoff.store(SkipIndex::kRetryEvery);              // a good index of other blocks exists: its whole-graph rebuild is not tried again on every scan
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true) || dbg_on())                        // once per process, whether or not BVG_DEBUG is set: every scan of these blocks is ~5x slower from here on
+            fprintf(stderr, "[bvg] warning: the residual skip index of blocks [%u, %u) could not be built (%s); scans of them run without it%s\n", blo, bhi,
+                    cause == SkipIndex::kStream ? "the checking kernels refused the stream" : "out of device memory or a HIP error",
+                    cause == SkipIndex::kStream ? " (bvg_build_index() tries again)" : " and try again every 8th time");
         return 0;
     };
     DevBuf cnt_d;
     const auto tb0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tb0).count(); };
-    if (cnt_d.alloc((size_t)nblk * sizeof(uint32_t)) || hipMemset(cnt_d.p, 0, (size_t)nblk * sizeof(uint32_t)) != hipSuccess) return give_up();
+    if (cnt_d.alloc((size_t)nblk * sizeof(uint32_t)) || hipMemset(cnt_d.p, 0, (size_t)nblk * sizeof(uint32_t)) != hipSuccess) return give_up(SkipIndex::kResources);
     g->skip_mode = 1; g->skip_cnt = (uint32_t*)cnt_d.p; g->skip_building = ix;          // (the counting pass counts in the new index's granularity)
     int r = run_decode(g, nfrom, nto, false, nullptr, nullptr, nullptr, nullptr, nullptr, &plp);
     g->skip_mode = 0; g->skip_cnt = nullptr; g->skip_building.reset();
     const double t_count = since();
     std::vector<uint32_t> cnt(nblk);
     if (!r && hipMemcpy(cnt.data(), cnt_d.p, (size_t)nblk * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) r = BVG_E_HIP;
-    if (r) return give_up();                                                      // a bad stream surfaces in the caller's own decode
+    if (r) return give_up((r == BVG_E_HIP || r == BVG_E_NOMEM) ? SkipIndex::kResources : SkipIndex::kStream);   // a bad stream surfaces in the caller's own decode
     std::vector<uint64_t> first(nblk + 1, 0);
     for (uint32_t i = 0; i < nblk; i++) first[i + 1] = first[i] + ((i >= blo && i < bhi) ? cnt[i] : 0u);
     const uint64_t total = first[nblk];
     if (hipMalloc(&ix->d_first, (size_t)(nblk + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc(&ix->d_bit, total * sizeof(uint16_t) + 16) != hipSuccess ||
         hipMalloc(&ix->d_fmt, nblk) != hipSuccess || hipMemset(ix->d_fmt, 0, nblk) != hipSuccess ||
-        hipMalloc(&ix->d_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16) != hipSuccess) return give_up();
-    if (hipMemcpy(ix->d_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return give_up();
+        hipMalloc(&ix->d_val, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16) != hipSuccess) return give_up(SkipIndex::kResources);
+    if (hipMemcpy(ix->d_first, first.data(), (size_t)(nblk + 1) * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return give_up(SkipIndex::kResources);
     // (entries nobody fills -- the allotment of a block that ends in the generic kernel -- read as zero: an index, and its file, are reproducible)
-    if (hipMemsetAsync(ix->d_bit, 0, total * sizeof(uint16_t) + 16, g->stream) != hipSuccess || hipMemsetAsync(ix->d_val, 0, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16, g->stream) != hipSuccess) return give_up();
+    if (hipMemsetAsync(ix->d_bit, 0, total * sizeof(uint16_t) + 16, g->stream) != hipSuccess || hipMemsetAsync(ix->d_val, 0, total * (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)) + 16, g->stream) != hipSuccess) return give_up(SkipIndex::kResources);
     ix->total = total;
     const double t_alloc = since();
     // Filling: a DENSE WALK writes the entries (bvg_index.hip: one lane per long list, the lists of a block queued together), then the validating pass decodes every block
@@ -483,7 +499,7 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
         wa.window = sh->p.window_size; wa.min_interval = sh->p.min_interval_length; wa.cod = codings_of(sh->p);
         wa.skip_first = ix->d_first; wa.skip_bit = ix->d_bit; wa.skip_val = ix->d_val; wa.skip_min = ix->skip_min; wa.skip_shift = ix->skip_shift;
         launch_index_walk(wa, bhi - blo, build_wide, g->stream);
-        if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up();
+        if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up(SkipIndex::kResources);
         t_walk = since();
     }
     g->skip_mode = dense_walk ? 3 : 2; g->skip_building = ix;
@@ -494,14 +510,14 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     if (!r && report) {
         // the pass decoded with the entries it was validating: the result says so (run_decode could not know their number yet)
         first_scan->index_entries = total;
-        first_scan->index_bytes += total * (2 + (build_wide ? sizeof(uint64_t) : sizeof(uint32_t))) + (uint64_t)(bhi - blo) * 9;
+        first_scan->index_bytes += total * (2 + (build_wide ? sizeof(uint64_t) : sizeof(uint32_t)));        // (the 9 bytes per block were counted by the pass itself: a.skip_first was set)
         if (first_scan_done) *first_scan_done = true;
     }
-    if (r) return give_up();
+    if (r) return give_up((r == BVG_E_HIP || r == BVG_E_NOMEM) ? SkipIndex::kResources : SkipIndex::kStream);
     launch_clear_unmarked_entries(ix->d_first, ix->d_fmt, ix->d_bit, ix->d_val, blo, bhi, build_wide, g->stream);
-    if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up();
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return give_up(SkipIndex::kResources);
     ix->h_fmt.resize(nblk);
-    if (hipMemcpy(ix->h_fmt.data(), ix->d_fmt, nblk, hipMemcpyDeviceToHost) != hipSuccess) return give_up();
+    if (hipMemcpy(ix->h_fmt.data(), ix->d_fmt, nblk, hipMemcpyDeviceToHost) != hipSuccess) return give_up(SkipIndex::kResources);
     ix->h_first.swap(first);
     if (dbg_on()) fprintf(stderr, "[bvg] residual skip index: blocks [%u, %u) of %u, %llu entries, %.1f MiB; wall clock: counting pass %.3f s, prefix + allocation %.3f s, dense walk %.3f s, %s pass %.3f s\n", blo, bhi, nblk, (unsigned long long)total, (double)total * (build_wide ? 10.0 : 6.0) / 1048576.0, t_count, t_alloc - t_count, t_walk - t_alloc, dense_walk ? "validating" : "filling + validating", since() - t_walk);
     return publish();
@@ -535,10 +551,13 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     // the whole graph once it covers a quarter of it.  bvg_build_index() does the same explicitly.
     if (!batch && rows_default && g->skip_mode == 0 && !knob("BVG_NOSKIP") && !g->tun.no_index && (to - from) >= 4096 && nblocks) {
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&plp->skip);
-        const bool covered = cur && cur->blk_lo <= lo && lo + nblocks <= cur->blk_hi;
+        bool covered = cur && cur->covers(lo, lo + nblocks), retry = false;
+        // a build that failed for want of memory is tried again every kRetryEvery-th scan of its blocks; so is the whole-graph rebuild behind a good partial index
+        if (cur && covered && cur->failed && cur->fail_cause == SkipIndex::kResources) { if (cur->backoff.load() <= 1) { covered = false; retry = true; } else cur->backoff.fetch_sub(1); }
+        else if (cur && !covered && !cur->failed && cur->backoff.load() > 0) { cur->backoff.fetch_sub(1); covered = true; }
         if (!covered && (!materialise || (to - from) >= sh->p.nodes / 4)) {
             bool scanned = false;
-            r = materialise ? build_skip(g, plp, 0, pl.nblk) : build_skip(g, plp, lo, lo + nblocks, false, res, from, to, &scanned);
+            r = materialise ? build_skip(g, plp, 0, pl.nblk, retry) : build_skip(g, plp, lo, lo + nblocks, retry, res, from, to, &scanned);
             if (r) return r;
             if (scanned) return 0;                              // the validating pass of the build WAS this scan (same nodes, the checking kernels: bit-exact by construction)
         }

@@ -357,7 +357,10 @@ int derive_offsets_parallel(const uint8_t* graph, uint64_t nbytes, int64_t n, in
     // rounds O(chunks) -- each with a detection pass over all chunks and two host syncs, quadratic in the stream -- before the caller
     // falls back to the sequential walk anyway.  Give up (-3) when the first mismatching chunk advanced by fewer than kSlowStep chunks
     // per round over the last kSlowRounds rounds, or when the rounds have used their time budget (30 s + 20 s per GiB of stream).
-    constexpr uint32_t kSlowRounds = 256, kSlowStep = 2;
+    // ONE chunk per round is not a stall: it is the crawl through the inside of a record with millions of residuals (a hub of a transposed or
+    // social graph), where only the chunk behind an exact one can be settled -- a one-workgroup launch per round, seconds for a record of
+    // thousands of chunks, where the sequential walk from bit 0 takes minutes per GiB (round 4 gave up there: ADVICE r4).
+    constexpr uint32_t kSlowRounds = 256, kSlowStep = 1;
     uint32_t mark_round = 0, mark_first = 0;
     const auto t_start = std::chrono::steady_clock::now();
     const double budget_s = 30.0 + 20.0 * (double)nbytes / (double)(1ull << 30);

@@ -118,7 +118,11 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
     __shared__ uint32_t slot_sh;
     if (tid == 0) {
         uint32_t sl = blockIdx.x;
-        if (a.gslots) { sl %= a.gnslots; while (atomicCAS(&a.gslots[sl], 0u, 1u) != 0u) sl = sl + 1u < a.gnslots ? sl + 1u : 0u; }
+        if (a.gslots) {
+            sl %= a.gnslots;
+            while (atomicCAS(&a.gslots[sl], 0u, 1u) != 0u) { sl = sl + 1u < a.gnslots ? sl + 1u : 0u; __builtin_amdgcn_s_sleep(2); }
+            __threadfence();              // acquire: what the previous holder of the area wrote is visible before this workgroup touches it.  (INVARIANT today: a workgroup never reads
+        }                                 //  bytes of pool / scr that it has not written itself, so nothing depends on this yet; a change that inherits contents would.)
         slot_sh = sl;
     }
     __syncthreads();
