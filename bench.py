@@ -172,9 +172,9 @@ def main():
                 # The bases are generated once PER NODE, by its local rank 0 (same seeds: identical on every node), and handed to the node's other ranks through a
                 # private directory (mode 0700, a random name that rank 0 broadcasts: nothing predictable in a world-writable place), removed whatever happens.
                 import secrets
-                tok = [secrets.token_hex(8) if rank == 0 else None]
-                dist.broadcast_object_list(tok, src=0)
-                sdir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bvg_bench_%s" % tok[0])
+                tok = torch.tensor([secrets.randbits(62) if rank == 0 else 0], dtype=torch.int64, device=cuda if cuda is not None else "cpu")
+                dist.broadcast(tok, src=0)                                # (a plain tensor collective: the same call on RCCL and on gloo)
+                sdir = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "bvg_bench_%016x" % int(tok.item()))
                 share = os.path.join(sdir, "b")
                 leader = int(os.environ.get("LOCAL_RANK", rank)) == 0
                 try:

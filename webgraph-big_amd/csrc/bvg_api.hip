@@ -837,6 +837,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             if (rekey || pd.dirty) {
                 std::vector<uint32_t> L[12];                                     // tier 0, four LDS classes, giants (5), the generic kernel (6); 7..11: tier 0 and the classes of the lean scan kernel
                 uint64_t gneed = 0, gnodes = 0, glong = 0;
+                const double cadmit = knob("BVG_CADMIT") ? atof(knob("BVG_CADMIT")) : 0.75;   // the same optimism for the lean classes (a block that fails its class is learned upward): +0.8 % on the default workload (profiles/r05_ab_cadmit.txt)
                 const double admit = knob("BVG_ADMIT") ? atof(knob("BVG_ADMIT")) : 0.3;   // share of a block's worst "list + window" that tier 0 of the scan kernel must hold
                 for (uint32_t i = 0; i < nblocks; i++) {
                     const uint64_t md = pl.h_maxd[lo + i] & 0x7FFFFFFFu;       // worst "list + window" of the block
@@ -846,7 +847,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                     int c;
                     if (long_record) c = 5;
                     else if (fastb ? ((uint64_t)((double)md * admit) + 64 <= af.lds_pool_elems + af.lds_scr_elems / 2) : need <= cap0) c = 0;   // (the lean kernel stores only the lists that are copied from: optimistic, the cascade teaches the rest)
-                    else { c = 1; while (c < 5 && (fastb ? lclasses : classes)[c - 1] < need) c++; }
+                    else { c = 1; const uint64_t cneed = fastb ? (uint64_t)((double)need * cadmit) : need; while (c < 5 && (fastb ? lclasses : classes)[c - 1] < cneed) c++; }
                     const int lrn = pd.learned[lo + i];                        // learned from an earlier scan's cascade
                     if (lrn > c) { c = lrn; if (c >= 5 && gneed < 65536) gneed = 65536; }
                     if (c == 5 && !giant_ok) c = 6;
