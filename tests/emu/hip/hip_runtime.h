@@ -101,6 +101,7 @@ inline void __threadfence() {}
 inline void __builtin_amdgcn_fence(int, const char*) {}
 inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier(); }
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (sh & 31u)); }   // v_alignbit_b32
 inline void __builtin_amdgcn_s_sleep(int) {}
 
 template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

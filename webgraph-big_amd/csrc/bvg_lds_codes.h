@@ -20,6 +20,14 @@ template <uint32_t MASK> __device__ __forceinline__ uint64_t win64(const uint32_
     const uint32_t a = sring[wi & MASK], b = sring[(wi + 1) & MASK], c = sring[(wi + 2) & MASK];
     return ((uint64_t)funnel(a, b, sh) << 32) | funnel(b, c, sh);
 }
+// win32 for rel >= 1 (every code but the first of a window: a residual code is never the first code of its record), as ONE v_alignbit_b32 (round 5).  The 32 bits from
+// bit `rel` on END in dword wj = (rel + 31) >> 5, 31 - ((rel + 31) & 31) bits above its low end: {dword wj - 1, dword wj} shifted right by ~(rel + 31) & 31, a shift of
+// 0 ... 31 that the instruction takes as it is.  (The plain form {dword wi, dword wi + 1} >> (32 - sh) needs a shift of 32 at sh = 0: the compiler turns it into
+// v_pk_mov + v_lshrrev_b64.)
+template <uint32_t MASK> __device__ __forceinline__ uint32_t win32p(const uint32_t* sring, uint32_t rel) {
+    const uint32_t q = rel + 31u, wj = q >> 5;
+    return __builtin_amdgcn_alignbit(sring[(wj - 1u) & MASK], sring[wj & MASK], ~q);
+}
 // gamma from a 64-bit window: value < 2^31 (length <= 63); returns length, 0 = does not fit
 __device__ __forceinline__ uint32_t gamma64(uint64_t w, uint64_t& val) {
     const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u;

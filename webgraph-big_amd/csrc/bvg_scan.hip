@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t t0 = q << kSkipShift;
                         const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) >> kSkipShift : 0u;      // the node's entries
                         cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
-                        trel[u] = tl[u] ? t_rel : 0u; r[u] = (T)((r0 - B) + nl); tpend[u] = t_pend;
+                        trel[u] = tl[u] ? t_rel : 1u; r[u] = (T)((r0 - B) + nl); tpend[u] = tl[u] ? t_pend : kInf;   // (a lane without task reads at bit 1: win32p wants rel >= 1)
                         tfirst[u] = (tl[u] && q == 0) ? 1u : 0u;
                         taddr[u] = t_dst == kInf ? kInf : t_dst + t0;
                         if (tl[u] && q) {
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                                 const uint64_t sv = reinterpret_cast<const uint64_t*>(a.skip_val)[ei] - (uint64_t)B;
                                 r[u] = (T)sv; if (sv >> 32) { tbad = true; cnt[u] = 0; }
                             } else r[u] = reinterpret_cast<const T*>(a.skip_val)[ei];
-                            if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 0; }
+                            if (!(trel[u] > t_rel && trel[u] < t_pend)) { tbad = true; cnt[u] = 0; trel[u] = 1; }
                         }
                         ivl[u] = kInf; ivn[u] = 0; ivk[u] = 0; ioff[u] = 0; tic2[u] = 0; tib2[u] = 0; t0a[u] = t0;
                         if (anyd2) {                                          // (wave-uniform: the shuffles are executed by every lane)
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 const bool has = rparse && nres > 0;
                 const bool anyd2 = D2 && OCC <= 5 && ballot(d2 && act) != 0;
                 bool tbad = false;
-                uint32_t cnt[1] = {has ? nres : 0u}, trel[1] = {has ? rel : 0u}, tpend[1] = {has ? pend : 0u}, tfirst[1] = {1u}, tk0[1] = {k0}, tk1[1] = {has ? k1d : 0u};
+                uint32_t cnt[1] = {has ? nres : 0u}, trel[1] = {has ? rel : 1u}, tpend[1] = {has ? pend : kInf}, tfirst[1] = {1u}, tk0[1] = {k0}, tk1[1] = {has ? k1d : 0u};
                 uint32_t taddr[1] = {(has && (stored || gl)) ? ((direct || d2) ? base : rtb) : kInf};
                 T r[1] = {(T)(x - B)};
                 uint32_t ivl[1] = {kInf}, ivn[1] = {0u}, ivk[1] = {0u}, ioff[1] = {0u}, tic2[1] = {0u}, tib2[1] = {0u}, t0a[1] = {0u};
