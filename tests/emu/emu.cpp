@@ -7,6 +7,7 @@
 // description: that is divergent control flow around a cross-lane operation, which the kernels here never do on purpose.
 #include <hip/hip_runtime.h>
 #include <execinfo.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <time.h>
 
@@ -121,9 +122,19 @@ void run_block() {
 
 unsigned char* dyn_lds() { return lds; }
 
+static void on_segv(int sig, siginfo_t* si, void*) {              // a wild access inside a kernel: say where (block, lane, address) before dying
+    fprintf(stderr, "emu: signal %d at address %p in block %u thread %u (%u threads per block, dynamic LDS %p + %zu); call stack:\n", sig, si->si_addr, g_block.x, cur, nthreads, (void*)lds, lds_bytes);
+    void* bt[32]; const int n = backtrace(bt, 32); backtrace_symbols_fd(bt, n, 2);
+    _exit(139);
+}
 void launch(const std::function<void()>& b, dim3 grid, dim3 block, size_t dyn_bytes) {
     static bool init = false;
-    if (!init) { init = true; const char* o = getenv("BVG_EMU_ORDER"); reverse_order = o && !strcmp(o, "rev"); }
+    if (!init) {
+        init = true; const char* o = getenv("BVG_EMU_ORDER"); reverse_order = o && !strcmp(o, "rev");
+        static char altstack[1 << 16];
+        stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof altstack; ss.ss_flags = 0; sigaltstack(&ss, nullptr);
+        struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_sigaction = on_segv; sa.sa_flags = SA_SIGINFO | SA_ONSTACK; sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr);
+    }
     if (body) { fprintf(stderr, "emu: nested or concurrent launch (the emulator is single-threaded)\n"); abort(); }
     nthreads = block.x * block.y * block.z;
     if (nthreads == 0 || grid.x == 0) return;

@@ -61,6 +61,16 @@ def test_kernels_under_address_sanitizer(flat):
     assert "emu case ok" in out
 
 
+def test_malformed_stream_suite_on_the_emulator(emu_lib):
+    """tests/test_malformed_streams.py -- hand-assembled records the encoder never writes (equal heads between the three streams, cap at d, over-running copy blocks,
+    negative residual counts), every tier and emission mode against the oracle -- is a GPU suite; the emulator runs its 56 GPU cases on the CPU, so the refusal and
+    fail-over logic of the kernels is exercised by the driver's CPU run too."""
+    e = dict(os.environ, BVG_HIP_LIB=emu_lib, BVG_TEST_KNOBS="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_malformed_streams.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                         env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 def test_dense_graph_through_the_emulated_kernels(emu_lib):
     out = run_case(6000, 5, "eu", 3)
     assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]

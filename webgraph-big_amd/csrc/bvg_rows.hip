@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
             if (act && ic > 0) { ivcur = scr[ib]; ivrem = (uint32_t)scr[ib + 1]; ivi = 1; }      // (act: a lane behind the row's cut has an interval count but no place in the scratch area -- tests/emu under AddressSanitizer)
             uint32_t rsi = 0;
             const T* const rtail = pool + rdst;                                    // the node's residual values
-            T rhead = nres ? rtail[0] : sentinel<T>();
+            T rhead = (act && nres) ? rtail[0] : sentinel<T>();                    // (act: a lane behind the row's cut has a residual count but no list: its `rdst` wraps)
             uint32_t j = 0;
             uint64_t chk = 0;
             for (;;) {
