@@ -16,7 +16,7 @@ timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 
 fi
 # kernel stats + timeline of steady-state scans (full-size default workload)
 rm -rf gpurun_out/r05_kt; mkdir -p gpurun_out/r05_kt
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_kt -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-verify --no-index-leg > $R/gpurun_out/r05_kt/bench.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r05_kt -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-verify --no-index-leg --no-real-leg > $R/gpurun_out/r05_kt/bench.log 2>&1 )
 f=$(ls gpurun_out/r05_kt/*/*_kernel_trace.csv | head -1)
 python3 profiles/r02/ktrace_summary.py $f > gpurun_out/r05_eu15_scan_timeline.txt; tail -12 gpurun_out/r05_eu15_scan_timeline.txt
 cp $(ls gpurun_out/r05_kt/*/*_kernel_stats.csv | head -1) gpurun_out/r05_eu15_kernel_stats.csv

@@ -12,7 +12,7 @@ SETS=${SETS:-4}; for set in "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREA
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU" \
            "FETCH_SIZE"; do
   i=$((i+1)); [ $i -gt $SETS ] && break
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py $args --steps 2 --warmup 2 --no-cpu-baseline --no-verify --no-index-leg > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $O/p$i.log; }
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/p$i -- python3 $R/bench.py $args --steps 2 --warmup 2 --no-cpu-baseline --no-verify --no-index-leg --no-real-leg > $O/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $O/p$i.log; }
 done
 cd $R
 python3 profiles/r03/pmc_summary.py $O | tee gpurun_out/r05_pmc_${tag}_summary.txt

@@ -11,6 +11,7 @@
 #include <sys/mman.h>
 #include <time.h>
 
+#include <mutex>
 #include <vector>
 
 namespace emu {
@@ -135,7 +136,9 @@ void launch(const std::function<void()>& b, dim3 grid, dim3 block, size_t dyn_by
         stack_t ss; ss.ss_sp = altstack; ss.ss_size = sizeof altstack; ss.ss_flags = 0; sigaltstack(&ss, nullptr);
         struct sigaction sa; memset(&sa, 0, sizeof sa); sa.sa_sigaction = on_segv; sa.sa_flags = SA_SIGINFO | SA_ONSTACK; sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr);
     }
-    if (body) { fprintf(stderr, "emu: nested or concurrent launch (the emulator is single-threaded)\n"); abort(); }
+    static std::mutex one_launch;                // host threads (the NodeIterator's helpers, bvg_scan_multi) launch one after the other: the lanes' state is global
+    std::lock_guard<std::mutex> lk(one_launch);
+    if (body) { fprintf(stderr, "emu: nested launch\n"); abort(); }
     nthreads = block.x * block.y * block.z;
     if (nthreads == 0 || grid.x == 0) return;
     if (nthreads > stacks_n) {

@@ -16,7 +16,7 @@ BENCH = os.path.join(ROOT, "bench.py")
 def _run(*extra):
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, BENCH, "--target-gib", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index-leg"] + list(extra),
+    r = subprocess.run([sys.executable, BENCH, "--target-gib", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index-leg", "--no-real-leg"] + list(extra),
                        capture_output=True, text=True, timeout=900, env=e)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
