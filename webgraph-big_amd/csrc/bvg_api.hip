@@ -553,8 +553,10 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&plp->skip);
         bool covered = cur && cur->covers(lo, lo + nblocks), retry = false;
         // a build that failed for want of memory is tried again every kRetryEvery-th scan of its blocks; so is the whole-graph rebuild behind a good partial index
-        if (cur && covered && cur->failed && cur->fail_cause == SkipIndex::kResources) { if (cur->backoff.load() <= 1) { covered = false; retry = true; } else cur->backoff.fetch_sub(1); }
-        else if (cur && !covered && !cur->failed && cur->backoff.load() > 0) { cur->backoff.fetch_sub(1); covered = true; }
+        // (the countdown is shared by every handle of the graph: a compare-exchange, so that two threads at 1 cannot wrap it)
+        auto tick = [](const SkipIndex& ix) { uint32_t b = ix.backoff.load(); while (b > 0 && !ix.backoff.compare_exchange_weak(b, b - 1)) {} return b; };   // the value before the tick
+        if (cur && covered && cur->failed && cur->fail_cause == SkipIndex::kResources) { if (tick(*cur) <= 1) { covered = false; retry = true; } }
+        else if (cur && !covered && !cur->failed && tick(*cur) > 0) covered = true;
         if (!covered && (!materialise || (to - from) >= sh->p.nodes / 4)) {
             bool scanned = false;
             r = materialise ? build_skip(g, plp, 0, pl.nblk, retry) : build_skip(g, plp, lo, lo + nblocks, retry, res, from, to, &scanned);

@@ -134,8 +134,6 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
     const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
-    const uint32_t nb_lo = (uint32_t)a.node_base;
-    const bool nbz = a.node_base == 0;
 
     for (unsigned i = tid; i < (unsigned)kRing; i += GNT) { nd_base[i] = 0; nd_d[i] = 0; }
     if (tid == 0) wg_bad = 0;
@@ -682,7 +680,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                 }
                 if (pe >= d) { zbad = true; pe = 0; }
                 out[pe] = vv;
-                if (!MAT && rep) chk += mix_node<T>(k0, k1, vv, nb_lo, nbz);
+                if (!MAT && rep) chk += mix_node<T>(k1, vv);
                 rt[i] = (T)pe;
             }
         }
@@ -726,7 +724,7 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
                     if (--krem == 0) MP::next_block(B, bc, rlen, qcur, krem, bi);   // MaskedLongIterator.java:81-100
                 }
                 out[p] = ov;
-                if (!MAT && rep) chk += mix_node<T>(k0, k1, ov, nb_lo, nbz);
+                if (!MAT && rep) chk += mix_node<T>(k1, ov);
             }
         }
         if (zbad) atomicOr(&wg_bad, 1u);

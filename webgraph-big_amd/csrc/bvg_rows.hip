@@ -77,8 +77,6 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = !GEN && zk >= 2;
     const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
-    const uint32_t nb_lo = (uint32_t)a.node_base;
-    const bool nbz = a.node_base == 0;
     constexpr bool LEAN = !MAT;                              // scan mode: unreferenced lists are not materialised
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
@@ -575,7 +573,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                         const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                         const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                         const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1), nl, 64);
-                        const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                        const uint32_t t_k1 = __shfl(k1, nl, 64);
                         const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
                         T v = 0; uint32_t len = 1, pe = 0; bool isiv = false;
                         if (tl) {
@@ -611,7 +609,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                             if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
                             else {
                                 if (t_fl & 1u) pool[t_ob + pe] = v;
-                                if (!MAT && (t_fl & 2u)) blk_chk += mix_node<T>(t_k0, t_k1, v, nb_lo, nbz);
+                                if (!MAT && (t_fl & 2u)) blk_chk += mix_node<T>(t_k1, v);
                                 rt[q - t_ic] = (T)pe;
                             }
                         }
@@ -651,7 +649,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                     const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                     const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1), nl, 64);
-                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                    const uint32_t t_k1 = __shfl(k1, nl, 64);
                     const bool t_stored = t_fl & 1u, t_rep = (t_fl >> 1) & 1u;
                     const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
                     uint32_t p = 0, pstop = 0, ri = 0, rnext = kInf, ivk = t_ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = t_bc;
@@ -687,7 +685,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                                 const T cv = rl[qcur < rlast ? qcur : rlast];
                                 const T v = ii ? (T)(ivleft + (T)io) : cv;
                                 if (t_stored) out[p] = v;
-                                if (!MAT && t_rep) blk_chk += mix_node<T>(t_k0, t_k1, v, nb_lo, nbz);
+                                if (!MAT && t_rep) blk_chk += mix_node<T>(t_k1, v);
                                 if (ii) {
                                     if (io + 1u == ivlen) {
                                         ivk++; ivpos = kInf; ivlen = 0;
@@ -737,7 +735,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
                     const uint32_t t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenN, nl, 64), t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64);
                     const uint32_t t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64), t_kept = __shfl(keptN, nl, 64), t_tk = __shfl(Tk, nl, 64), t_iv = __shfl(ivN, nl, 64);
-                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1r = __shfl(rep ? k1 : 0u, nl, 64);     // a node outside [from,to) sums nothing
+                    const uint32_t t_k1r = __shfl(rep ? k1 : 0u, nl, 64);     // a node outside [from,to) sums nothing
                     const T* const rl = pool + t_rlb;
                     uint32_t cnt = 0, qcur = 0, krem = kInf, bi = t_bc, ivk = 0, ivrem = 0; bool iota = false; T ivv = 0;
                     if (tl) {
@@ -765,7 +763,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                         cnt_leaf++;
                         const T cv = rl[qcur < rlast ? qcur : rlast];
                         const T v = iota ? ivv : cv;
-                        csum += mix_node<T>(t_k0, todo ? t_k1r : 0u, v, nb_lo, nbz);
+                        csum += mix_node<T>(todo ? t_k1r : 0u, v);
                         if (todo) {
                             if (iota) {
                                 ivv++;
@@ -829,7 +827,7 @@ __global__ void __launch_bounds__(64, TASK ? BVG_TASK_WAVES : BVG_ROWS_WAVES) ro
                     if (stored) out[j] = m;
                     j++;
                     __hip_atomic_store(&produced[lane], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    if (!MAT && rep) chk += m == sentinel<T>() ? (uint64_t)k1 * (~0ull - a.node_base) : mix_node<T>(k0, k1, m, nb_lo, nbz);   // (-1 where the merge ran dry, BVG:1164-1176: the per-node constant adds the base to every arc)
+                    if (!MAT && rep) chk += m == sentinel<T>() ? (uint64_t)k1 * (~0ull - a.node_base) : mix_node<T>(k1, m);   // (-1 where the merge ran dry, BVG:1164-1176: the per-node constant adds the base to every arc)
                     if (cneed && c == m) {                                        // MaskedLongIterator.java:81-100
                         rpos++;
                         if (--keep == 0) {

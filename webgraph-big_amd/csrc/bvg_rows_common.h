@@ -107,12 +107,10 @@ template <typename T> struct MaskPrefix {
     }
 };
 
-// checksum term of successor m (an id RELATIVE to the kernel's base: node_base, or the block base of a wide graph) of a node whose key is
-// k1: k1 * m -- one v_mad_u64_u32 for 32-bit lists.  mix_keyed(k0, k1, m + base) = this + (k1 * base + k0), and the bracket is added once per
-// node, times its outdegree (mix_node_const, bvg_device.h).  (kA, nbl, nbz: the old definition's key pieces, unused.)
-template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t /*kA*/, uint32_t k1, T m, uint32_t /*nbl*/, bool /*nbz*/) {
-    return (uint64_t)k1 * (uint64_t)m;
-}
+// checksum term of successor m (an id RELATIVE to the kernel's base: node_base, or the block base of a wide graph) of a node whose key is k1: k1 * m -- one
+// v_mad_u64_u32 for 32-bit lists.  mix_keyed(k0, k1, m + base) = this + (k1 * base + k0), and the bracket is added once per node, times its outdegree
+// (mix_node_const, bvg_device.h).
+template <typename T> __device__ __forceinline__ uint64_t mix_node(uint32_t k1, T m) { return (uint64_t)k1 * (uint64_t)m; }
 
 // ordering point for LDS traffic inside ONE wavefront (its lanes run in lock step and its LDS operations complete in
 // order): only the compiler has to be kept from moving accesses across it

@@ -120,14 +120,14 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
     return pos;
 }
 
-// NBZ: the node base is 0 (no carry handling in the checksum key); Z3: zeta_3 residuals (the specialised decoder)
+// Z3: zeta_3 residuals (the specialised decoder)
 // OCC: wavefronts per SIMD the register allocation leaves room for -- 4 (128 VGPRs: nothing spills, 16 wavefronts per CU) or 6 (85 VGPRs, a
 // handful of spills, 24 per CU: sparse graphs, whose lists need little LDS, gain 9 % from the extra wavefronts; profiles/r03_ab_w20.txt)
 // MAT: the materialising form behind nodeIterator() / successorBigArray() (BVG:1164-1176, a.succ / a.cum / a.outdeg): every list of a reported
 // node is written to the output -- lists that are copied from and lists without reference are built in LDS exactly as in scan mode and copied
 // out in coalesced runs; a LEAF with a reference (most nodes) is merged straight into the output by the same position tasks (its parked
 // residuals and its block / interval entries are all it needs of LDS); nothing is summed (no checksum: the caller gets the arcs).
-template <bool NBZ, bool Z3, bool WIDE, int OCC, bool D2, bool MAT>
+template <bool Z3, bool WIDE, int OCC, bool D2, bool MAT>
 __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
     __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
@@ -162,8 +162,6 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     // the 64-bit row kernel.  The checksum takes the base like a node base (mix_node: m + base, carries included).
     const int64_t B = WIDE ? (s > (int64_t)a.wide_half ? s - (int64_t)a.wide_half : 0) : 0;
     const uint64_t nbase = a.node_base + (uint64_t)B;
-    const uint32_t nb_lo = (uint32_t)nbase;
-    constexpr bool nbz = NBZ;
 
     for (unsigned i = lane; i < (unsigned)kRing; i += 64) { nd_base[i] = 0; nd_d[i] = 0; }
     wave_sync();
@@ -596,7 +594,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 for (uint32_t p0 = 0; p0 < Ttot; p0 += RP) {
                     BVG_WC(6, 1);
                     const uint32_t tq9p = BVG_T0();
-                    bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk0[RU], tk1[RU]; T r[RU];
+                    bool tl[RU]; uint32_t cnt[RU], trel[RU], tpend[RU], tfirst[RU], taddr[RU], tk1[RU]; T r[RU];
                     uint32_t ivl[RU], ivn[RU], ivk[RU], ioff[RU], tic2[RU], tib2[RU], t0a[RU];   // lists decoded in place around their intervals (d2)
                     const bool anyd2 = D2 && OCC <= 5 && ballot(d2 && act) != 0;
 #pragma unroll
@@ -615,7 +613,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
                         const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? ((direct || d2) ? base : rtb) : (gl ? rtb : kInf), nl, 64), t_ef = __shfl(efirst, nl, 64);
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
-                        tk0[u] = __shfl(k0, nl, 64); tk1[u] = tl[u] ? s_k1 : 0u;
+                        tk1[u] = tl[u] ? s_k1 : 0u;
                         const uint32_t t0 = q << kSkipShift;
                         const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) >> kSkipShift : 0u;      // the node's entries
                         cnt[u] = tl[u] ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;             // the last segment takes the remainder
@@ -661,7 +659,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 const bool has = rparse && nres > 0;
                 const bool anyd2 = D2 && OCC <= 5 && ballot(d2 && act) != 0;
                 bool tbad = false;
-                uint32_t cnt[1] = {has ? nres : 0u}, trel[1] = {has ? rel : 1u}, tpend[1] = {has ? pend : kInf}, tfirst[1] = {1u}, tk0[1] = {k0}, tk1[1] = {has ? k1d : 0u};
+                uint32_t cnt[1] = {has ? nres : 0u}, trel[1] = {has ? rel : 1u}, tpend[1] = {has ? pend : kInf}, tfirst[1] = {1u}, tk1[1] = {has ? k1d : 0u};
                 uint32_t taddr[1] = {(has && (stored || gl)) ? ((direct || d2) ? base : rtb) : kInf};
                 T r[1] = {(T)(x - B)};
                 uint32_t ivl[1] = {kInf}, ivn[1] = {0u}, ivk[1] = {0u}, ioff[1] = {0u}, tic2[1] = {0u}, tib2[1] = {0u}, t0a[1] = {0u};
@@ -697,7 +695,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                             if (jk < ic) { jl = (uint32_t)scr[ib + 2 * jk]; jn = (uint32_t)scr[ib + 2 * jk + 1] & 0xFFFFu; } else jl = kInf;
                         }
                         if (stored || gl) pool[((direct || d2) ? base : rtb) + t + joff] = r;
-                        if (!MAT) csum += mix_node<T>(k0, k1d, r, nb_lo, nbz);
+                        if (!MAT) csum += mix_node<T>(k1d, r);
                         if (rr > pend) { bad = true; break; }
                     }
                 }
@@ -768,11 +766,11 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                             t_gl = s_gl != 0; gp = a.succ + (((uint64_t)g_hi << 32) | g_lo);
                         }
                         T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false, isfill = false;
-                        uint32_t f_k0 = 0, f_k1 = 0;
+                        uint32_t f_k1 = 0;
                         if (anyf) {                                           // (wave-uniform: the shuffles are executed by every lane)
                             const int s_f = __shfl((int)(memf ? 1 : 0), nl, 64);      // (hoisted: `tl && __shfl()` would run the shuffle under a lane mask)
                             isfill = tl && s_f != 0;
-                            f_k0 = __shfl(k0, nl, 64); f_k1 = __shfl(k1, nl, 64);
+                            f_k1 = __shfl(k1, nl, 64);
                         }
                         if (isfill) {                                         // an interval of a list decoded in place: its start was recorded when the residuals passed it
                             vv = scr[t_ib + 2 * q]; const T pk = scr[t_ib + 2 * q + 1];
@@ -805,7 +803,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                         wave_sync();                                      // the parked values have been read: positions may replace them
                         if (tl && len) {
-                            if (isfill) { for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); if (!MAT) fsum += mix_node<T>(f_k0, f_k1, (T)(vv + i), nb_lo, nbz); } }
+                            if (isfill) { for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); if (!MAT) fsum += mix_node<T>(f_k1, (T)(vv + i)); } }
                             else if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
                             else { if (MAT && t_gl) gp[pe] = (int64_t)((uint64_t)vv + nbase); else pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
                         }
@@ -851,7 +849,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     const uint32_t t_d = __shfl(d, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenS, nl, 64);
                     const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                     const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
-                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                    const uint32_t t_k1 = __shfl(k1, nl, 64);
                     const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
                     bool t_gl = false; int64_t* gp = nullptr;
                     if (MAT) {
@@ -903,7 +901,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         if (MAT) { if (emit) { if (t_gl) gp[p] = (int64_t)((uint64_t)vv + nbase); else out[p] = vv; } }
                         else {
                             if (emit) out[p] = vv;
-                            zsum += mix_node<T>(t_k0, emit ? t_k1 : 0u, vv, nb_lo, nbz);
+                            zsum += mix_node<T>(emit ? t_k1 : 0u, vv);
                         }
                         const bool cp = emit && !ii;                                      // a copied element: MaskedLongIterator.java:81-100
                         qcur += cp ? 1u : 0u; krem -= cp ? 1u : 0u;
@@ -961,7 +959,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 const uint32_t e_len = e_hi & 0xFFFFFFu;
                 const uint32_t nch = (e_len + kChunk - 1u) / kChunk;
                 const uint32_t cincl = wave_incl_scan32(nch), cs = cincl - nch, Ctot = lane_get(cincl, 63);
-                const uint32_t e_k0 = __shfl(k0, (int)((e_hi >> 24) & 63u), 64), e_k1 = __shfl(k1, (int)((e_hi >> 24) & 63u), 64);
+                const uint32_t e_k1 = __shfl(k1, (int)((e_hi >> 24) & 63u), 64);
                 for (uint32_t p0 = 0; p0 < Ctot; p0 += 64) {
                     const bool tl = p0 + lane < Ctot;
                     const uint32_t own = task_owner(cincl, p0 + lane);           // (every lane takes part in the shuffles)
@@ -969,7 +967,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     const uint32_t s_first = (uint32_t)__shfl((int)cs, sl, 64);
                     const uint32_t q = tl ? p0 + lane - s_first : 0u;
                     const uint32_t c_lo = __shfl(e_lo, sl, 64), c_hi = __shfl(e_hi, sl, 64);
-                    const uint32_t c_k0 = __shfl(e_k0, sl, 64), c_k1 = __shfl(e_k1, sl, 64);
+                    const uint32_t c_k1 = __shfl(e_k1, sl, 64);
                     const uint32_t c_len = c_hi & 0xFFFFFFu, o = q * kChunk;
                     const uint32_t n = tl ? (c_len - o < kChunk ? c_len - o : kChunk) : 0u;
                     const bool iota = (c_hi >> 31) != 0u;
@@ -984,10 +982,10 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 #endif
                     for (uint32_t i = 0; i < nmax; i += 4) {
                         const T v0 = src[i], v1 = src[i + 1], v2 = src[i + 2], v3 = src[i + 3];   // (reads past a run stay inside the LDS allocation)
-                        lsum += mix_node<T>(c_k0, i < n ? c_k1 : 0u, iota ? (T)(b0 + i) : v0, nb_lo, nbz);
-                        lsum += mix_node<T>(c_k0, i + 1 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 1) : v1, nb_lo, nbz);
-                        lsum += mix_node<T>(c_k0, i + 2 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 2) : v2, nb_lo, nbz);
-                        lsum += mix_node<T>(c_k0, i + 3 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 3) : v3, nb_lo, nbz);
+                        lsum += mix_node<T>(i < n ? c_k1 : 0u, iota ? (T)(b0 + i) : v0);
+                        lsum += mix_node<T>(i + 1 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 1) : v1);
+                        lsum += mix_node<T>(i + 2 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 2) : v2);
+                        lsum += mix_node<T>(i + 3 < n ? c_k1 : 0u, iota ? (T)(b0 + i + 3) : v3);
                     }
                     blk_chk += lsum;
                     BVG_T1(11, tqL2);
@@ -1051,16 +1049,15 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 size_t scan_static_lds() { return (size_t)kRing * 4; }
 
 template <int OCC, bool D2> static void launch_scan_occ(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
-    const bool nbz = a.node_base == 0, z3 = a.cod.zeta_k == 3;
-    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else if (nbz) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<true, false, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    const bool z3 = a.cod.zeta_k == 3;
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, true, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<true, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, OCC, D2, false>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
-// the materialising form: no checksum, so the node base only shifts what is written (one instantiation for every base)
+// the materialising form: no checksum
 template <bool D2> static void launch_scan_mat(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
     const bool z3 = a.cod.zeta_k == 3;
-    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, true, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, true, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
-    else { if (z3) hipLaunchKernelGGL((scan_kernel<false, true, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
+    if (wide) { if (z3) hipLaunchKernelGGL((scan_kernel<true, true, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, true, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
+    else { if (z3) hipLaunchKernelGGL((scan_kernel<true, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, bool materialise, hipStream_t s) {

@@ -70,8 +70,6 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
     uint32_t* const glist = gres + kFlowRes;
     const uint32_t W = (uint32_t)a.window, zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
-    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
-    const bool nbz = a.node_base == 0;
     const uint32_t stage_bits = kFlowAux * 32u;
 
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
@@ -202,8 +200,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
             const bool rep = mine && x >= rep_lo && x < rep_hi;
             uint32_t k0 = 0, k1 = 0;
             if (rep) {
-                const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-                k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
+                node_key((uint64_t)x + a.node_base, k0, k1);
             }
             if (parse && !bad && !malf && ic > 0) {                               // intervals (BVG:1042-1058): they fix the number of residuals
                 int64_t prev = 0;
@@ -275,7 +272,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                         const int nl = (int)(ent & 63u); const uint32_t q = ent >> 8;
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
                         const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(rbl, nl, 64), t_ef = __shfl(efirst, nl, 64);
-                        const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                        const uint32_t t_k1 = __shfl(k1, nl, 64);
                         const uint32_t t0 = q * kSkipEvery;
                         const uint32_t t_ce = t_nres >= kSkipMin ? (t_nres - 1u) / kSkipEvery : 0u;
                         const uint32_t cnt0 = tl ? (q == t_ce ? t_nres - t0 : kSkipEvery) : 0u;
@@ -298,7 +295,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                                 trel += len;
                                 r = (t0 + i) == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
                                 ring[t_dst + t0 + i] = r;
-                                chk += mix_node<T>(t_k0, t_k1, r, nb_lo, nbz);      // (k1 = 0 for nodes outside the reported range)
+                                chk += mix_node<T>(t_k1, r);      // (k1 = 0 for nodes outside the reported range)
                                 if (trel > t_pend) { err |= ERR_OVERRUN; cnt = 0; }
                             }
                         }
@@ -316,7 +313,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                         rel += len;
                         r = t == 0 ? (T)(r + (T)nat2int64(val)) : (T)(r + 1 + (T)val);
                         ring[rbl + t] = r;
-                        chk += mix_node<T>(k0, k1, r, nb_lo, nbz);
+                        chk += mix_node<T>(k1, r);
                         if (rel > pend) { err |= ERR_OVERRUN; break; }
                     }
                     if (rel != pend && !bad) err |= ERR_MALFORMED;               // SURVEY A.6 self-check
@@ -340,7 +337,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                 for (uint32_t t = lane; t < k * 8u; t += 64) hg[t] = ring[t];
                 wave_sync();
             }
-            if (rep) { blk_arcs += d; blk_nodes += 1; }
+            if (rep) { blk_arcs += d; blk_nodes += 1; blk_chk += mix_node_const(k0, k1, a.node_base, d); }   // (round 5's checksum: k1 * successor per arc + d * (k1 * base + k0) per node)
             boff_run += btot + lane_get(iincl, 63);
             roff_run += lane_get(rincl, 63);
             wave_sync();
@@ -406,13 +403,12 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                     const bool rep = fl & 2u, stored = fl & 4u;
                     uint32_t k0 = 0, k1 = 0;
                     if (rep) {
-                        const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-                        k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
+                        node_key((uint64_t)x + a.node_base, k0, k1);
                     }
                     uint32_t ivtot = 0;
                     for (uint32_t kk = 0; kk < ic; kk++) {                        // interval elements into the checksum
                         const uint32_t lf = aiv[2 * kk], ln = aiv[2 * kk + 1];
-                        if (rep) for (uint32_t jj = lane; jj < ln; jj += 64) chk += mix_node<T>(k0, k1, (T)(lf + jj), nb_lo, nbz);
+                        if (rep) for (uint32_t jj = lane; jj < ln; jj += 64) chk += mix_node<T>(k1, (T)(lf + jj));
                         ivtot += ln;
                     }
                     const uint32_t kept = d - nres - ivtot;                       // copied elements (0 without a reference)
@@ -524,7 +520,7 @@ __global__ void __launch_bounds__(64, 5) flow_kernel(DecodeArgs a, uint32_t nwor
                             const uint64_t km = ballot(keptq);
                             if (!km) continue;
                             const T v = keptq ? rd(q) : (T)0;
-                            if (rep) chk += mix_node<T>(k0, keptq ? k1 : 0u, v, nb_lo, nbz);
+                            if (rep) chk += mix_node<T>(keptq ? k1 : 0u, v);
                             if (stored) {
                                 const uint32_t t = tbase + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
                                 // extras in front of kept element t: residuals with c <= t (c non-decreasing: upper bound), intervals with c <= t

@@ -52,8 +52,6 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
-    const uint32_t nb_lo = (uint32_t)a.node_base, nb_hi = (uint32_t)(a.node_base >> 32);
-    const bool nbz = a.node_base == 0;
     constexpr uint32_t HS = sizeof(T) * 4;                                    // interval entry: length | position << HS
     const T HM = (T)(((T)1 << HS) - 1);
 
@@ -350,8 +348,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
         const bool rep = act && x >= rep_lo && x < rep_hi;
         uint32_t k0 = 0, k1 = 0;
         if (rep) {
-            const uint64_t kx = splitmix64((uint64_t)x + a.node_base); k1 = (uint32_t)(kx >> 32) | 1u;
-            k0 = (uint32_t)kx + nb_lo + nb_hi * 0x9E3779B1u;
+            node_key((uint64_t)x + a.node_base, k0, k1);
         }
         {
             uint32_t rlbN = 0, rlenN = 0;
@@ -392,7 +389,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                         const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                         const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                         const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1), nl, 64);
-                        const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                        const uint32_t t_k1 = __shfl(k1, nl, 64);
                         const T* const rl = pool + t_rlb; T* const rt = pool + t_rtb;
                         T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false;
                         if (tl) {
@@ -428,7 +425,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                             if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
                             else {
                                 if (t_fl & 1u) pool[t_ob + pe] = vv;
-                                if (t_fl & 2u) blk_chk += mix_node<T>(t_k0, t_k1, vv, nb_lo, nbz);
+                                if (t_fl & 2u) blk_chk += mix_node<T>(t_k1, vv);
                                 rt[q - t_ic] = (T)pe;
                             }
                         }
@@ -464,7 +461,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                     const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ic = __shfl(ic, nl, 64), t_ib = __shfl(ib, nl, 64);
                     const uint32_t t_nres = __shfl(nresN, nl, 64), t_rtb = __shfl(rtbN, nl, 64), t_ob = __shfl(base, nl, 64);
                     const uint32_t t_fl = __shfl((uint32_t)stored | ((uint32_t)rep << 1), nl, 64);
-                    const uint32_t t_k0 = __shfl(k0, nl, 64), t_k1 = __shfl(k1, nl, 64);
+                    const uint32_t t_k1 = __shfl(k1, nl, 64);
                     const bool t_stored = t_fl & 1u, t_rep = (t_fl >> 1) & 1u;
                     const T* const rl = pool + t_rlb; const T* const rt = pool + t_rtb; T* const out = pool + t_ob;
                     uint32_t p = 0, pstop = 0, ri = 0, rnext = kInf, ivk = t_ic, ivpos = kInf, ivlen = 0, qcur = 0, krem = kInf, bi = t_bc;
@@ -495,7 +492,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                                 const T cv = rl[qcur < rlast ? qcur : rlast];
                                 const T ov = ii ? (T)(ivleft + (T)io) : cv;
                                 if (t_stored) out[p] = ov;
-                                if (t_rep) blk_chk += mix_node<T>(t_k0, t_k1, ov, nb_lo, nbz);
+                                if (t_rep) blk_chk += mix_node<T>(t_k1, ov);
                                 if (ii) {
                                     if (io + 1u == ivlen) {
                                         ivk++; ivpos = kInf; ivlen = 0;
@@ -518,7 +515,7 @@ __global__ void __launch_bounds__(64 * NW) rows_wg_kernel(DecodeArgs a) {
                 const uint32_t fl = wg_flags;
                 if (fl) { failed = true; fail_need = fl; break; }
             }
-            if (rep && wv == 0) { blk_arcs += d; blk_nodes += 1; }
+            if (rep && wv == 0) { blk_arcs += d; blk_nodes += 1; blk_chk += mix_node_const(k0, k1, a.node_base, d); }
         }
 
         __syncthreads();

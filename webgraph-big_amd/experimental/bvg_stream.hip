@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(64) stream_kernel(DecodeArgs a) {
                         m_refnb[slot] = h_ref | (h_nb << 8); m_sb[slot] = h_sb; m_ni[slot] = h_ni; m_pi[slot] = h_pi;
                         m_nr[slot] = h_nr; m_pr[slot] = rel; m_pe[slot] = pend;
                         const bool prep = px >= rep_lo && px < rep_hi;
-                        if (!MAT) { const uint64_t kx = splitmix64((uint64_t)(hs + px) + a.node_base); m_k0[slot] = (uint32_t)kx; m_k1[slot] = (uint32_t)(kx >> 32) | 1u; }
+                        if (!MAT) { uint32_t q0, q1; node_key((uint64_t)(hs + px) + a.node_base, q0, q1); m_k0[slot] = q0; m_k1[slot] = q1; }
                         else m_out[slot] = prep ? (a.batch ? a.cum[bid >> 1] : a.cum[hs + px - a.from]) : 0;
                     }
                     if (ballot(bad)) { failed = true; break; }
