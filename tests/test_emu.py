@@ -71,6 +71,14 @@ def test_malformed_stream_suite_on_the_emulator(emu_lib):
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
+def test_randomised_parity_of_the_lean_kernels_on_the_emulator(emu_lib):
+    """tests/emu/fuzz_flat.py: random shapes, windows, reference-chain depths, interval lengths, zeta k, LDS geometries (small pools: sub-rows and compaction), records per
+    super-row and lane orders; scan_kernel and the experimental flat kernel against the oracle (8 cases here; 90 ran on the final round-5 tree: BVG_EMU_FUZZ=<n> for more)."""
+    n = os.environ.get("BVG_EMU_FUZZ", "8")
+    out = subprocess.run([sys.executable, os.path.join(EMU, "fuzz_flat.py"), n, "5"], capture_output=True, text=True, timeout=3000)
+    assert out.returncode == 0 and " 0 failed" in out.stdout, out.stdout[-3000:] + out.stderr[-1500:]
+
+
 def test_dense_graph_through_the_emulated_kernels(emu_lib):
     out = run_case(6000, 5, "eu", 3)
     assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]
