@@ -55,6 +55,9 @@ using namespace rows;
 #define BVG_SCAN_CHUNK 8
 #endif
 constexpr uint32_t kNoList = 0xFFFFu;
+// keeps a short wave-uniform `if` a branch: the raised phi-folding thresholds of the Makefile would turn it into selects that every step pays for
+// (an empty volatile asm cannot be speculated; tests/emu strips it)
+#define BVG_KEEP_BRANCH(x) asm volatile("" : "+v"(x));
 #ifndef BVG_SCAN_MINTASK
 #define BVG_SCAN_MINTASK 1
 #endif
@@ -153,6 +156,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     uint32_t* const stage_w = reinterpret_cast<uint32_t*>(pool + CAP);       // the window over the stream: read by every sub-row of a super-row
     const uint32_t* const stage = stage_w;
     const uint32_t stage_bits = a.lds_stage_words * 32u;
+    const uint32_t sbitw = (uint32_t)(reinterpret_cast<const unsigned char*>(stage_w) - dyn_lds) << 3;   // the window's first bit, counted from the start of the dynamic LDS
     const uint32_t zk = (uint32_t)a.cod.zeta_k, minint = (uint32_t)a.min_interval;
     const bool zfast = zk >= 2;
     const uint32_t kSkipMin = a.skip_min, kSkipShift = a.skip_shift, kSkipEvery = 1u << kSkipShift;   // (this index's granularity: they hide the compile-time defaults of bvg_kernels.h)
@@ -340,26 +344,56 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 // two blocks per step -- a kept one and the skipped one behind it -- from one 64-bit window: the longest block list of the 64
                 // records sets the number of steps (28 on the eu15 shape, 8 % of the scan at one block per step: profiles/r03_ab_dummyhdr.txt).
                 // A block of 2^16 - 1 elements or more fails the block here (no list of this kernel is that long).
-                for (uint32_t i = 0; i < bc; i += 2) {
-                    const uint64_t w = win64<LIN>(stage, rel);
-                    const uint32_t lz1 = w ? (uint32_t)__builtin_clzll(w) : 64u;
-                    const bool two = i + 1u < bc;
-                    const uint32_t l1 = 2u * (lz1 & 15u) + 1u;
-                    const uint64_t w2 = w << l1;
-                    const uint32_t lz2 = w2 ? (uint32_t)__builtin_clzll(w2) : 64u;
-                    if (lz1 >= 16u || (two && lz2 >= 16u) || rel > pend) { bad = true; bc = i; break; }
-                    const uint32_t l2 = 2u * lz2 + 1u;
-                    const uint32_t b1 = (uint32_t)(w >> (64u - l1)) - (i ? 0u : 1u);        // (gamma value + 1 = the top l1 bits; the first block is not biased)
-                    const uint32_t b2 = (uint32_t)(w2 >> (64u - (l2 & 63u)));               // (value + 1: every block but the first is at least 1)
+                // Round 6: both codes from ONE 32-bit window when they fit it (each of up to 31 bits, 32 together: blocks of fewer than ~2^7 elements, nearly all of
+                // them) -- two dword reads and a funnel shift instead of three reads and 64-bit shifts; a lane whose pair does not fit takes the 64-bit form of the
+                // step.  The loop takes PAIRS (a kept block and the skipped one behind it); the last block of an odd count follows it.  `tot` and `copied` start
+                // at -1: every block but the first is stored minus 1 (BVG:1025), so adding (gamma value + 1) = the code's top bits is right for all of them.
+                uint32_t tbh = sbitw + rel - 1u;                              // running bit address of the next code, minus one (as in bvg_scan_steps3.inc)
+                const uint32_t tbend = sbitw + pend - 1u;
+                tot = 0xFFFFFFFFu; copied = 0xFFFFFFFFu;
+                uint32_t i = 0;
+                for (; i + 1u < bc && tbh <= tbend; i += 2) {
+                    const uint32_t* const wp = reinterpret_cast<const uint32_t*>(dyn_lds + ((tbh >> 3) & ~3u));
+                    const uint32_t w = __builtin_amdgcn_alignbit(wp[0], wp[1], ~tbh);
+                    const uint32_t z1 = (uint32_t)__builtin_clz(w | 0x10000u), l1 = 2u * z1 + 1u;      // <= 15 zeros, <= 31 bits
+                    const uint32_t w2 = w << l1;
+                    const uint32_t z2 = (uint32_t)__builtin_clz(w2 | 0x10000u), l2 = 2u * z2 + 1u;
+                    uint32_t b1 = w >> (32u - l1), b2 = w2 >> (32u - l2);     // gamma value + 1 = the top bits of the code
+                    uint32_t adv = l1 + l2;
+                    if (__builtin_expect((w < w2 ? w : w2) < 0x10000u || adv > 32u, 0)) {
+                        const uint64_t w6 = win64<LIN>(stage, tbh + 1u - sbitw);
+                        const uint32_t lz1 = w6 ? (uint32_t)__builtin_clzll(w6) : 64u;
+                        const uint32_t m1 = 2u * (lz1 & 15u) + 1u;
+                        const uint64_t w62 = w6 << m1;
+                        const uint32_t lz2 = w62 ? (uint32_t)__builtin_clzll(w62) : 64u;
+                        const uint32_t m2 = 2u * (lz2 & 15u) + 1u;
+                        bad |= lz1 >= 16u || lz2 >= 16u;                      // a block of 2^16 - 1 elements or more fails the block here (no list of this kernel is that long)
+                        b1 = (uint32_t)(w6 >> (64u - m1)); b2 = (uint32_t)(w62 >> (64u - m2));
+                        adv = m1 + m2;
+                    }
                     tot += b1; copied += b1;
                     // straight in PREFIX form (MaskPrefix): end position of block i in the referenced list | elements kept up to and including it
-                    scr[sb + i] = MaskPrefix<T>::pack(tot, copied);
-                    if (two) { tot += b2; scr[sb + i + 1u] = MaskPrefix<T>::pack(tot, copied); }
-                    rel += l1 + (two ? l2 : 0u);
+                    const T e1 = MaskPrefix<T>::pack(tot, copied);
+                    tot += b2;
+                    scr[sb + i] = e1; scr[sb + i + 1u] = MaskPrefix<T>::pack(tot, copied);
+                    tbh += adv;
 #ifdef BVG_EXP_DUMMY_HDR
                     { uint32_t dm = i; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY_HDR; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
 #endif
                 }
+                if (i < bc && tbh <= tbend) {                                 // the last block of an odd number
+                    const uint64_t w6 = win64<LIN>(stage, tbh + 1u - sbitw);
+                    const uint32_t lz1 = w6 ? (uint32_t)__builtin_clzll(w6) : 64u;
+                    const uint32_t m1 = 2u * (lz1 & 15u) + 1u;
+                    bad |= lz1 >= 16u;
+                    const uint32_t b1 = (uint32_t)(w6 >> (64u - m1));
+                    tot += b1; copied += b1;
+                    scr[sb + i] = MaskPrefix<T>::pack(tot, copied);
+                    tbh += m1; i++;
+                }
+                bad |= i < bc;                                                // (the loop stops at the record's end: blocks left over are a malformed record)
+                if (bc == 0) { tot = 0; copied = 0; }
+                rel = tbh + 1u - sbitw;
                 rlenN = nd_d[(uint32_t)(x - ref) & RM];
                 if (big != 0 || tot > rlenN || tot > 0xFFFFu) { bad = true; tot = rlenN; }   // (cannot happen in a validated block)
                 if (!(bc & 1)) copied += rlenN - tot;                         // BVG:1030
@@ -402,19 +436,40 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         if (parse) {
             if (ic > 0) {
                 uint32_t prev = 0;
-                for (uint32_t i = 0; i < ic; i++) {
-                    uint64_t v1, v2;
-                    const uint32_t l1 = gamma_at(stage, rel, v1);
-                    const uint32_t l2 = gamma_at(stage, rel + l1, v2);
-                    if (l1 == 0 || l2 == 0 || rel > pend) { bad = true; ic = i; break; }
-                    rel += l1 + l2;
+                // Round 6: left end and length from ONE 32-bit window when the two gamma codes fit it (as in the copy-block loop above)
+                uint32_t tbi = sbitw + rel - 1u;
+                const uint32_t tiend = sbitw + pend - 1u;
+                uint32_t i = 0;
+                for (; i < ic && tbi <= tiend; i++) {
+                    const uint32_t* const wp = reinterpret_cast<const uint32_t*>(dyn_lds + ((tbi >> 3) & ~3u));
+                    const uint32_t w = __builtin_amdgcn_alignbit(wp[0], wp[1], ~tbi);
+                    const uint32_t z1 = (uint32_t)__builtin_clz(w | 0x10000u), l1 = 2u * z1 + 1u;
+                    const uint32_t w2 = w << l1;
+                    const uint32_t z2 = (uint32_t)__builtin_clz(w2 | 0x10000u), l2 = 2u * z2 + 1u;
+                    uint32_t u1 = (w >> (32u - l1)) - 1u, u2 = (w2 >> (32u - l2)) - 1u;      // the two gamma values
+                    uint64_t v1 = u1;                                         // (WIDE only: the left gap at full width)
+                    uint32_t adv = l1 + l2;
+                    if (__builtin_expect((w < w2 ? w : w2) < 0x10000u || adv > 32u, 0)) {
+                        const uint32_t r1 = tbi + 1u - sbitw;
+                        uint64_t v2;
+                        const uint32_t m1 = gamma_at(stage, r1, v1);
+                        const uint32_t m2 = gamma_at(stage, r1 + m1, v2);
+                        if (m1 == 0 || m2 == 0) { bad = true; v1 = 0; v2 = 0; }
+                        big |= (uint32_t)(v1 >> 32) | (uint32_t)(v2 >> 23) | (uint32_t)(v2 >> 32);   // (a run descriptor holds 24 bits of length: leave a longer interval to the row kernel)
+                        u1 = (uint32_t)v1; u2 = (uint32_t)v2;
+                        adv = m1 + m2;
+                    }
+                    tbi += adv;
 #ifdef BVG_EXP_DUMMY_IV
                     { uint32_t dm = i; _Pragma("unroll") for (int z = 0; z < BVG_EXP_DUMMY_IV; z++) asm volatile("v_xad_u32 %0, %0, %0, %0" : "+v"(dm)); if (dm == 0x12345u) err |= 1u; }
 #endif
-                    big |= (uint32_t)(v1 >> 32) | (uint32_t)(v2 >> 23) | (uint32_t)(v2 >> 32);   // (a run descriptor holds 24 bits of length: leave a longer interval to the row kernel)
-                    const uint32_t u1 = (uint32_t)v1;
-                    const uint32_t leftv = i == 0 ? (uint32_t)(x - B) + ((u1 >> 1) ^ (0u - (u1 & 1u))) : prev + 1u + u1;   // nat2int, modulo 2^32
-                    const uint32_t len = (uint32_t)v2 + minint;
+                    uint32_t leftv = prev + 1u + u1;
+                    if (i == 0) {                                             // (wave-uniform) the first left end is relative to the node, signed (BVG:1047)
+                        uint32_t l0 = (uint32_t)(x - B) + ((u1 >> 1) ^ (0u - (u1 & 1u)));    // nat2int, modulo 2^32
+                        BVG_KEEP_BRANCH(l0);
+                        leftv = l0;
+                    }
+                    const uint32_t len = u2 + minint;
                     if (WIDE) {                                               // the interval must lie inside the block's 2^32 ids
                         const int64_t lt = i == 0 ? (x - B) + nat2int64(v1) : (int64_t)(uint64_t)prev + 1 + (int64_t)v1;
                         big |= (uint32_t)(((uint64_t)lt) >> 32) | (uint32_t)(((uint64_t)lt + len) >> 32);
@@ -424,6 +479,8 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     bad |= extra < 0;                                         // (checked at every step: the difference must not wrap)
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
+                bad |= i < ic;                                                // (stopped at the record's end with intervals left over)
+                rel = tbi + 1u - sbitw;
                 if (extra < 0 || big != 0) { bad = true; extra = 0; }
             }
             nres = (uint32_t)extra;
@@ -640,7 +697,11 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                     }
                     BVG_T1(14, tq9p);
+                    if constexpr (Z3 && RU == 1) {
+#include "bvg_scan_steps3.inc"
+                    } else {
 #include "bvg_scan_steps.inc"
+                    }
                 }
                 };
 #ifndef BVG_SCAN_RU2_FROM
@@ -650,7 +711,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 // and its registers are what the 85-VGPR instantiation of the sparse graphs spills (44 -> 31 spilled VGPRs without it: cnr-2000 +3.4 %, web +2.4 %, profiles/r04_ab_noru2*.txt)
                 if (OCC == 4 && Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
                 bad |= tbad;
-            } else if (OCC == 6 ? ballot(rparse && nres > 0) != 0 : false) {
+            } else if ((OCC == 6 || Z3) ? ballot(rparse && nres > 0) != 0 : false) {
                 // no list of the sub-row is long enough for skip entries: one task per lane, the residuals of its own node, through the same branch-free
                 // step loop.  Sparse graphs (the 85-VGPR instantiation) only: +1.0 % on cnr-2000, +0.7 % on `web`, 16 instead of 31 spilled registers
                 // (profiles/r04_ab_lpn5_*.txt; as a lambda shared with the task passes +1.6 / +1.9 %, but then the dense instantiations lose 0.5 %:
@@ -665,10 +726,14 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 uint32_t ivl[1] = {kInf}, ivn[1] = {0u}, ivk[1] = {0u}, ioff[1] = {0u}, tic2[1] = {0u}, tib2[1] = {0u}, t0a[1] = {0u};
                 if (anyd2 && has && d2) { tic2[0] = ic; tib2[0] = ib; ivl[0] = (uint32_t)scr[ib]; ivn[0] = (uint32_t)scr[ib + 1] & 0xFFFFu; }
 #ifndef BVG_ABLATE_LPN
+                if constexpr (Z3) {
+#include "bvg_scan_steps3.inc"
+                } else {
 #include "bvg_scan_steps.inc"
+                }
 #endif
                 bad |= tbad;
-            } else if (OCC != 6 && rparse) {
+            } else if (OCC != 6 && !Z3 && rparse) {
                 if (nres > 0) {
                     T r = (T)(x - B);
                     uint32_t rr = rel;
