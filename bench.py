@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the per-tile checksum gate against the CPU oracle")
     ap.add_argument("--no-real-leg", action="store_true", help="skip the second, untimed-for-`value` workload behind the timed region: the REAL web graph cnr-2000 tiled to 4 GiB (`real_graph` in the line)")
     ap.add_argument("--no-index-leg", action="store_true", help="skip the three index-less scans behind the timed region (value_no_index)")
+    ap.add_argument("--no-wide-leg", action="store_true", help="skip the three scans through the 64-bit-id path behind the timed region (value_wide)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on a one-GPU box)")
     ap.add_argument("--echo-ranks", action="store_true", help="plumbing test: every rank prints 'rank r of w' and exits before touching the GPU")
     ap.add_argument("--verify-whole", action="store_true", help="strong scaling: rank 0 also scans the whole graph in one piece (untimed) and compares it with the reduced {arcs, chk}")
@@ -325,6 +326,24 @@ def main():
         if dist is not None:
             no_index["s_per_step"] = S.allreduce_max(tn, device=cuda)
 
+    # ---- the same scan at the reference's width (behind the timed region): BVGraph computes successors in `long`; the headline runs the 32-bit successor kernels, which is
+    # lossless below 2^32 - 256 nodes (dtype "u32").  A flyweight with bvg_tuning.force_wide = 1 scans the same stream through the 64-bit-id path (its own skip index with
+    # 64-bit values; the scan kernel on lists of ids relative to a per-block base, the checking kernels on 64-bit lists): same checksum, its own rate
+    wide = None
+    if not args.no_wide_leg and n_graph <= 0xFFFFFF00:
+        gw = g.copy(); gw.set_tuning(block_bits=args.block_bits, force_wide=True); gw.set_node_base(g.node_base())
+        for _ in range(2):                                                # (index build of the wide form + tier learning)
+            rw = gw.scan(lo, hi)
+        assert (rw["arcs"], rw["chk"]) == (int(r["arcs"]), int(r["chk"])), "the 64-bit-id scan disagrees with the 32-bit one"
+        torch.cuda.synchronize(); tw0 = time.perf_counter()
+        for _ in range(3):
+            rw = gw.scan(lo, hi)
+        torch.cuda.synchronize(); tw = (time.perf_counter() - tw0) / 3
+        wide = {"s_per_step": tw, "lean_blocks": int(rw["lean_blocks"]), "slow_blocks": int(rw["slow_blocks"]), "index_entries": int(rw["index_entries"])}
+        del gw
+        if dist is not None:
+            wide["s_per_step"] = S.allreduce_max(tw, device=cuda)
+
     # ---- a REAL web graph beside the stand-in (behind the timed region; never part of `value`): the reference's own fixture cnr-2000 (LAW; 9.9 arcs per node, 24 % empty
     # nodes, reference chains of depth 3), its stream repeated on the device to 4 GiB, gated tile by tile against the CPU oracle, 3 warm-up + 8 timed scans
     real = None
@@ -380,6 +399,11 @@ def main():
                                "how": "bvg_copy() flyweight with bvg_tuning.no_index = 1: same stream, plan and offsets in HBM, no skip entries, no validation marks (every block on the checking kernels)"}
             gain = no_index["s_per_step"] - steady_s
             out["index_break_even_scans"] = (out["index_build_s"] / gain) if gain > 0 else None
+        if wide is not None:
+            out["value_wide"] = tot_arcs / wide["s_per_step"]
+            out["wide"] = {"ms_per_step": wide["s_per_step"] * 1e3, "steps": 3, "dtype": "u64 ids (lists relative to a per-block base in the scan kernel; 64-bit lists on the checking kernels)",
+                           "lean_blocks": wide["lean_blocks"], "slow_blocks": wide["slow_blocks"], "index_entries": wide["index_entries"],
+                           "how": "bvg_copy() flyweight with bvg_tuning.force_wide = 1 on the same stream: the path a graph beyond 2^32 - 256 nodes takes; same {arcs, chk} asserted"}
         t = measured_pmc(args.basename or args.shape, copies, args.base_nodes, world, scaling)
         if t:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = t["hbm_bytes_per_launch"], t.get("source")

@@ -284,11 +284,24 @@ int bvg_abi_version(void);
  * chk = sum of bvg_arc_mix over all arcs, mod 2^64: commutative, so node-range shards reduce with
  * a plain sum (one RCCL all-reduce of {arcs, chk}).  Linear in y under the node's key: a kernel pays
  * one 32 x 32 + 64 multiply-add per successor (the reference's SpeedTest.java:127-135 does nothing
- * with them) and adds d * k0 per node; a single wrong, missing, surplus or misattributed successor
- * always changes the sum (k1 is odd, keys differ between nodes); two errors inside ONE node that
- * cancel in the sum of its successors do not -- the materialising parity tests are the primary gate,
- * this is the scan's self-check.  (Rounds 1-4 used a non-linear mix: six vector instructions per arc,
- * a quarter of what a decoded successor has to cost.) */
+ * with them) and adds d * k0 per node.
+ * WHAT THE SCAN MUST DO (round 6, the contract the timed region is held to): ONE multiply-add per
+ * PRODUCED successor -- every decoded residual, every element of an interval, every element a copy
+ * block keeps, leaf or stored list alike, is read (or generated) and multiplied on its own.  The
+ * linear form has closed forms over runs (len * left + len (len - 1) / 2 for an interval, a
+ * difference of prefix sums for a kept block): the kernels never use one -- that would be work
+ * skipped.  The only per-node constants folded are d * k0 and d * k1 * base (base = the node base /
+ * block base every id of the block is stored relative to).  tests/test_gpu_checksum_integrity.py
+ * changes ONE element of a stored list and checks that every node copying it moves by exactly
+ * k1(node) * delta, through the lean kernel.
+ * WHAT IT DETECTS: a single wrong, missing, surplus or misattributed successor changes the sum
+ * unless k1 * dy + (0 or k0) == 0 mod 2^64 -- never for one wrong value with |dy| < 2^63 (k1 is
+ * odd), with probability ~2^-32 for a missing / surplus / misattributed one (32-bit keys; nodes
+ * whose 32-bit hashes collide share a key).  Two errors inside ONE node that cancel in the sum of
+ * its successors are invisible: the materialising parity tests (every successor against the oracle
+ * / the golden) are the primary gate, this is the scan's self-check; bench.py --verify also decodes
+ * tiles through bvg_decode_range, which does not rely on linearity.  (Rounds 1-4 used a non-linear
+ * mix: six vector instructions per arc, a quarter of what a decoded successor has to cost.) */
 uint64_t bvg_arc_mix(uint64_t x, uint64_t y);
 
 #ifdef __cplusplus

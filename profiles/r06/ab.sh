@@ -6,7 +6,7 @@ out=gpurun_out/r06_ab_${TAG:-x}.txt; : > $out
 IFS=';' read -ra CFG <<< "$CONFIGS"
 size=""; [ "${GIB:-4}" != "0" ] && size="--target-gib ${GIB:-4}"
 for c in "${CFG[@]}"; do
-  r=$(env $c BVG_DEBUG=1 timeout -k 10 400 python bench.py --shape ${SHAPE:-eu15} $size --steps ${STEPS:-5} --warmup 3 --no-cpu-baseline --no-verify --no-index-leg --no-real-leg ${ARGS} 2> gpurun_out/r06_ab.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f G edges/s  %.2f ms/step' % (d['value']/1e9, d['ms_per_step']))")
+  r=$(env $c BVG_DEBUG=1 timeout -k 10 400 python bench.py --shape ${SHAPE:-eu15} $size --steps ${STEPS:-5} --warmup 3 --no-cpu-baseline --no-verify --no-index-leg --no-wide-leg --no-real-leg ${ARGS} 2> gpurun_out/r06_ab.err | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f G edges/s  %.2f ms/step' % (d['value']/1e9, d['ms_per_step']))")
   k=$(grep -E "(scan|flat) kernel:" gpurun_out/r06_ab.err | tail -1 | sed "s/.*kernel: //")
   t=$(grep -E "tiers concurrent" gpurun_out/r06_ab.err | tail -1 | sed 's/.*tiers concurrent: //')
   echo "[$c] $r | $k | $t" | tee -a $out

@@ -1086,7 +1086,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     { std::vector<uint32_t> none; r = run_global_tier(false, none); if (r) return r; }
     if (d_work) (void)hipFree(d_work);
 
-    unsigned long long acc[28];
+    unsigned long long acc[32];
     launch_reduce_acc(g->d_acc, kAccStripes, g->stream);
     HIPCHK(hipMemcpyAsync(acc, g->d_acc, sizeof acc, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
@@ -1111,6 +1111,8 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         fprintf(stderr, "[bvg] scan kernel work: levels %llu | Z1 passes %llu tasks %llu | Z2 passes %llu tasks %llu steps %llu positions %llu | residual task passes %llu steps %llu residuals %llu, "
                 "lane-per-node steps %llu residuals %llu | leaf item passes %llu chunk passes %llu steps(x4) %llu elements %llu\n",
                 acc[9], acc[12], acc[25], acc[10], acc[11], acc[13], acc[14], acc[15], acc[16], acc[17], acc[18], acc[26], acc[27], acc[20], acc[21], acc[24]);
+    if ((a.dbg & 64u) && (acc[28] | acc[29]))
+        fprintf(stderr, "[bvg] scan kernel work, headers: copy-block loop steps (pairs) %llu for %llu blocks | interval loop steps %llu for %llu intervals\n", acc[28], acc[30], acc[29], acc[31]);
 #endif
     if (res) {
         res->arcs = acc[0]; res->chk = acc[1]; res->nodes = acc[2];

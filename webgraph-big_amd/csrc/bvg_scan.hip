@@ -185,27 +185,32 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     //  8 residuals decoded by tasks, 9 steps of the lane-per-node residual loop, 10 leaf chunk passes, 11 leaf loop steps (4 elements each),
     //  12 leaf elements, 13 Z1 tasks, 14 residuals of the lane-per-node loop, 15 leaf item passes}
     uint32_t cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cyc2[4] = {0, 0, 0, 0};                         // round 6: {0 steps of the copy-block loop (pairs), 1 steps of the interval loop, 2 copy blocks, 3 intervals}
 #define BVG_T0() 0u
 #define BVG_T1(i, t) do { (void)(t); } while (0)
 #define BVG_WC(i, n) do { cyc[i] += (uint32_t)(n); } while (0)
 #define BVG_WCL(i, n) do { cyc[i] += wave_sum32((uint32_t)(n)); } while (0)
+#define BVG_WC2(i, n) do { cyc2[i] += (uint32_t)(n); } while (0)
 #elif defined(BVG_MARKS)
     // `hipcc -S -DBVG_MARKS`: the section boundaries as comments in the assembly (static instruction counts per section)
 #define BVG_T0() ([]() { asm volatile("; BVGMARK begin"); return 0u; }())
 #define BVG_T1(i, t) do { (void)(t); asm volatile("; BVGMARK end %0" :: "n"(i)); } while (0)
 #define BVG_WC(i, n) do { } while (0)
 #define BVG_WCL(i, n) do { } while (0)
+#define BVG_WC2(i, n) do { } while (0)
 #elif defined(BVG_PROF)
     uint32_t cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define BVG_T0() ((uint32_t)clock64())
 #define BVG_T1(i, t) do { cyc[i] += (uint32_t)clock64() - (t); } while (0)
 #define BVG_WC(i, n) do { } while (0)
 #define BVG_WCL(i, n) do { } while (0)
+#define BVG_WC2(i, n) do { } while (0)
 #else
 #define BVG_T0() 0u
 #define BVG_T1(i, t) do { (void)(t); } while (0)
 #define BVG_WC(i, n) do { } while (0)
 #define BVG_WCL(i, n) do { } while (0)
+#define BVG_WC2(i, n) do { } while (0)
 #endif
 
     // residual skip index: entries of this block
@@ -338,6 +343,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 #if defined(BVG_PROF) && defined(BVG_PROF_WORK)
         uint32_t ncop_sim = 0;
 #endif
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+        { const bool pb = parse && lane < K1 && ref > 0; BVG_WC2(0, wave_max32(pb ? bc >> 1 : 0u)); BVG_WC2(2, wave_sum32(pb ? bc : 0u)); }
+#endif
         if (parse && lane < K1) {
             if (ref > 0) {
                 uint32_t copied = 0, tot = 0;
@@ -433,11 +441,14 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         ib = CAPe + iincl - iw;
         parse = parse && lane < K1;
         // ---- D1: intervals (BVG:1042-1058): they fix the number of residuals
+#if defined(BVG_PROF) && defined(BVG_PROF_WORK)
+        { BVG_WC2(1, wave_max32(parse ? ic : 0u)); BVG_WC2(3, wave_sum32(parse ? ic : 0u)); }
+#endif
         if (parse) {
             if (ic > 0) {
                 uint32_t prev = 0;
                 // Round 6: left end and length from ONE 32-bit window when the two gamma codes fit it (as in the copy-block loop above)
-                uint32_t tbi = sbitw + rel - 1u;
+                uint32_t tbi = sbitw + rel - 1u, negacc = 0;
                 const uint32_t tiend = sbitw + pend - 1u;
                 uint32_t i = 0;
                 for (; i < ic && tbi <= tiend; i++) {
@@ -476,10 +487,10 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     }
                     prev = leftv + len;
                     extra -= (int32_t)len;
-                    bad |= extra < 0;                                         // (checked at every step: the difference must not wrap)
+                    negacc |= (uint32_t)extra;                                // (checked at every step: the difference must not wrap)
                     scr[ib + 2 * i] = (T)leftv; scr[ib + 2 * i + 1] = (T)len;
                 }
-                bad |= i < ic;                                                // (stopped at the record's end with intervals left over)
+                bad |= i < ic || (negacc >> 31) != 0u;                                                // (stopped at the record's end with intervals left over)
                 rel = tbi + 1u - sbitw;
                 if (extra < 0 || big != 0) { bad = true; extra = 0; }
             }
@@ -1103,6 +1114,9 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             for (int i = 0; i < 10; i++) atomicAdd(&a.acc[9 + i], (unsigned long long)cyc[i]);
             atomicAdd(&a.acc[20], (unsigned long long)cyc[10]); atomicAdd(&a.acc[21], (unsigned long long)cyc[11]);
             for (int i = 12; i < 16; i++) atomicAdd(&a.acc[12 + i], (unsigned long long)cyc[i]);
+#ifdef BVG_PROF_WORK
+            for (int i = 0; i < 4; i++) atomicAdd(&a.acc[28 + i], (unsigned long long)cyc2[i]);
+#endif
         }
 #endif
     }
