@@ -43,12 +43,18 @@ def main():
                    piv=float(rng.choice([0.0, 0.3, 0.7])), maxd=int(rng.choice([300, 3000, 20000])))
         env = dict(os.environ, BVG_HIP_LIB=os.path.join(HERE, "libbvgraph_emu.so"), BVG_TEST_KNOBS="1", BVG_FLAT=str(int(rng.random() < 0.7)), BVG_FLAT_RECS=str(int(rng.choice([64, 128, 256]))),
                    BVG_EMU_ORDER=str(rng.choice(["fwd", "rev"])))
+        # scan_kernel's list builds (BVG_DBG): 0 = position tasks, 8192 = ZE (kept-element tasks over the extras' bit vectors), 4096 = WW (experimental wave-wide build), both
+        lb = int(rng.choice([0, 8192, 8192, 4096, 12288])) if env["BVG_FLAT"] == "0" or os.environ.get("BVG_FUZZ_DBG") else 0
+        if os.environ.get("BVG_FUZZ_DBG"):
+            lb = int(os.environ["BVG_FUZZ_DBG"]); env["BVG_FLAT"] = "0"
+        if lb:
+            env["BVG_DBG"] = str(lb)
         if rng.random() < 0.5:
             env["BVG_SCAN_POOL"] = str(int(rng.choice([512, 640, 1024]))); env["BVG_SCAN_SCR"] = str(int(rng.choice([192, 320, 448])))
         p = subprocess.run([sys.executable, "-c", CHILD % sub], env=env, capture_output=True, text=True, timeout=1200)
         ok = p.returncode == 0 and "ok lean_blocks" in p.stdout
         lean_cases += int(ok and not p.stdout.strip().endswith(" 0"))
-        print("case %d %s flat=%s recs=%s order=%s pool=%s %s n=%d dense=%s: %s" % (c, "ok" if ok else "FAILED", env["BVG_FLAT"], env["BVG_FLAT_RECS"], env["BVG_EMU_ORDER"], env.get("BVG_SCAN_POOL", "-"), kw, sub["n"], dense,
+        print("case %d %s flat=%s recs=%s order=%s pool=%s dbg=%s %s n=%d dense=%s: %s" % (c, "ok" if ok else "FAILED", env["BVG_FLAT"], env["BVG_FLAT_RECS"], env["BVG_EMU_ORDER"], env.get("BVG_SCAN_POOL", "-"), env.get("BVG_DBG", "0"), kw, sub["n"], dense,
                                                                               p.stdout.strip()[-40:] if ok else (p.stdout[-300:] + p.stderr[-1500:])), flush=True)
         bad += int(not ok)
     print("emu fuzz: %d cases, %d failed, %d ran the lean kernels" % (cases, bad, lean_cases))

@@ -110,6 +110,8 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v
 template <typename T> inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+template <typename T> inline T atomicXor(T* p, T v) { T o = *p; *p = o ^ v; return o; }
+inline unsigned atomicXor(unsigned* p, unsigned v) { unsigned o = *p; *p = o ^ v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
@@ -133,6 +135,10 @@ template <typename T> inline T __shfl_xor(T v, int mask, int = 64) { return emu_
 template <typename T> inline T __shfl_up(T v, unsigned delta, int = 64) { const int l = (int)(threadIdx.x & 63u); return emu_lane_read(v, l >= (int)delta ? l - (int)delta : l); }
 template <typename T> inline T __shfl_down(T v, unsigned delta, int = 64) { const int l = (int)(threadIdx.x & 63u); return emu_lane_read(v, l + (int)delta < 64 ? l + (int)delta : l); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_lane_read(v, lane); }
+// v_mbcnt_lo / _hi: set bits of the mask word below this lane (+ add); inverse ballot: this lane's bit of a wave-uniform mask
+inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t m, uint32_t add) { const unsigned l = threadIdx.x & 63u; return add + (uint32_t)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
+inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t m, uint32_t add) { const unsigned l = threadIdx.x & 63u; return add + (l > 32 ? (uint32_t)__builtin_popcount(m & ((1u << (l - 32)) - 1u)) : 0u); }
+inline bool __builtin_amdgcn_inverse_ballot_w64(uint64_t m) { return (m >> (threadIdx.x & 63u)) & 1ull; }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu_lane_read(v, 0); }     // (every kernel here calls it with all lanes active)
 // v_mov_b32 with a DPP control as bvg_device.h uses it: row_shr:n (0x110 + n), row_bcast:15 (0x142), row_bcast:31 (0x143); lanes that are masked off
 // (row_mask / bank_mask) or have no source keep `old` (bound_ctrl = false)

@@ -586,7 +586,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     a.fail_list = g->d_fail + 1; a.fail_count = g->d_fail; a.fail_cap = g->fail_cap; a.fail_need = g->d_fail + 1 + g->fail_cap;
     a.dbg = knob("BVG_DBG") ? (uint32_t)strtoul(knob("BVG_DBG"), nullptr, 10) : 0;
 #ifndef BVG_PROF
-    a.dbg &= (16u | 32u | 64u);                             // forcing an emission form and the work counters leave the results alone; the
+    a.dbg &= (16u | 32u | 64u | 4096u | 8192u | 0xFFFF0000u);             // forcing an emission form (16, 32; 4096 / 8192: scan_kernel's opt-in list builds) and the work counters leave the results alone; the
                                                             // phase-skipping bits (1, 2, 4, 128) exist in the profiling build only
 #endif
     // The COUNTING pass of the index build needs the record headers only (a node's entry count follows from its residual count): the

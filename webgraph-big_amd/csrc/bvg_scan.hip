@@ -152,8 +152,36 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     // blocks and intervals, at the very top, as large as this super-row needs (a fixed scratch area stood 60 % empty on average): what the
     // scratch does not take, the sub-rows get.  `scr` indexes the same area; sb / ib are absolute.
     T* const scr = pool;
-    const uint32_t CAP = a.lds_pool_elems + a.lds_scr_elems;
-    uint32_t* const stage_w = reinterpret_cast<uint32_t*>(pool + CAP);       // the window over the stream: read by every sub-row of a super-row
+    // WW (round 6, scan mode of the dense instantiations): a stored list WITH reference is built wave-wide, one list after the other, from lane bit vectors (below, "WW");
+    // the bit vector (the copy mask over the referenced list, then the positions of the extras in the list being built) takes kWWWords dwords off the top of the area
+#ifdef BVG_EXPERIMENTAL
+    constexpr bool WWT = !MAT && OCC <= 5;                                   // (`make experimental` and the emulator only: it lost, see below)
+#else
+    constexpr bool WWT = false;
+#endif
+    constexpr uint32_t kWWBits = 1024, kWWWords = kWWBits / 32;              // lists and referenced lists of up to 1 024 elements (longer ones keep the position tasks)
+    // MEASURED (profiles/r06_ab_ww3_*.txt, r06_ww_on_eu15_2g_pmc_summary.txt): eu15 302 -> 270 G edges/s with every such list built this way, 287 / 297 / 298 G from 128 / 256 / 512
+    // elements on; uk 218 -> 179.  The vector instructions do drop (1.59 -> 1.40 per arc) but the scalar ones rise (0.75 -> 1.01) and every list is a serial chain of LDS round
+    // trips and scalar prefix steps (~3 000 cycles for a list of 100): vector-issue utilisation falls from 92 % to 71 % -- the wavefront's own critical path becomes the bound.
+    // Opt-in in the experimental build only: BVG_DBG = 4096 + (shortest list << 16).
+    const bool wwon = WWT && (a.dbg & 4096u) != 0;
+    const uint32_t CAPfull = a.lds_pool_elems + a.lds_scr_elems;
+    // ZE (round 6, scan mode): the position tasks of a level walk the KEPT elements only; where the extras lie in the lists being built is a bit vector per list (set by the
+    // extras pass), and a copied element's place is the next clear bit.  The bit vectors of one level's lists live in kZEWords dwords off the top of the area.
+    // MEASURED (profiles/r06_ab_ze_*.txt, r06_ze_on_eu15_2g_pmc_summary.txt against r06_mid_eu15_2g_pmc_summary.txt): eu15 304 -> 294 G edges/s, cnr 142 -> 137, uk 220 -> 218.
+    // The position loop does shrink (no step on a residual's place, 33 instead of 43 instructions per step), but the intervals then have to be written by the extras pass, a lane
+    // each and element by element -- ~25 steps of a 64-wide pass for one lane's work -- and the bit vectors cost a zeroing, an atomic per extra, a select per task and 3 % of the
+    // pool: 1.556 vector instructions per arc against 1.517.  Opt-in in the experimental build only (BVG_DBG = 8192).
+#ifdef BVG_EXPERIMENTAL
+    const bool zeon = !MAT && (a.dbg & 8192u) != 0;
+#else
+    constexpr bool zeon = false;
+#endif
+    const uint32_t kZEWords = 32u + (CAPfull >> 6);
+    const uint32_t CAP = CAPfull - (wwon ? kWWWords : 0u) - (zeon ? kZEWords : 0u);
+    uint32_t* const wwm = reinterpret_cast<uint32_t*>(pool + CAP);
+    uint32_t* const zem = reinterpret_cast<uint32_t*>(pool + CAP + (wwon ? kWWWords : 0u));
+    uint32_t* const stage_w = reinterpret_cast<uint32_t*>(pool + CAPfull);   // the window over the stream: read by every sub-row of a super-row
     const uint32_t* const stage = stage_w;
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t sbitw = (uint32_t)(reinterpret_cast<const unsigned char*>(stage_w) - dyn_lds) << 3;   // the window's first bit, counted from the start of the dynamic LDS
@@ -339,7 +367,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         const uint32_t bbase = CAP - btot;
         sb = bbase + bincl - bc;
         // ---- B: copy blocks (BVG:1023-1032) and C: interval count (BVG:1040)
-        uint32_t rlenN = 0;
+        uint32_t rlenN = 0, ncopN = 0;                                        // the referenced list's length; elements copied from it (BVG:1030)
 #if defined(BVG_PROF) && defined(BVG_PROF_WORK)
         uint32_t ncop_sim = 0;
 #endif
@@ -405,7 +433,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 rlenN = nd_d[(uint32_t)(x - ref) & RM];
                 if (big != 0 || tot > rlenN || tot > 0xFFFFu) { bad = true; tot = rlenN; }   // (cannot happen in a validated block)
                 if (!(bc & 1)) copied += rlenN - tot;                         // BVG:1030
-                extra = (int32_t)d - (int32_t)copied;
+                extra = (int32_t)d - (int32_t)copied; ncopN = copied;
 #if defined(BVG_PROF) && defined(BVG_PROF_WORK)
                 ncop_sim = copied;
 #endif
@@ -720,7 +748,13 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 #endif
                 // Two chains per lane only in the 128-VGPR instantiation: on the final structure the two-chain form measures flat there (thresholds 64 ... never: profiles/r04_ab_t0wait.txt),
                 // and its registers are what the 85-VGPR instantiation of the sparse graphs spills (44 -> 31 spilled VGPRs without it: cnr-2000 +3.4 %, web +2.4 %, profiles/r04_ab_noru2*.txt)
-                if (OCC == 4 && Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
+                // (round 6: not for zeta_3 -- its one-chain step loop, bvg_scan_steps3.inc, issues 33 vector instructions per step against 63 per chain of the interleaved form)
+#ifdef BVG_Z3_RU2
+                constexpr bool ru2z3 = true;                                  // (A/B builds: the two-chain form for zeta_3 too)
+#else
+                constexpr bool ru2z3 = false;
+#endif
+                if ((!Z3 || ru2z3) && OCC == 4 && Ttot > (uint32_t)BVG_SCAN_RU2_FROM) task_passes(std::integral_constant<uint32_t, 2>{}); else task_passes(std::integral_constant<uint32_t, 1>{});
                 bad |= tbad;
             } else if ((OCC == 6 || Z3) ? ballot(rparse && nres > 0) != 0 : false) {
                 // no list of the sub-row is long enough for skip entries: one task per lane, the residuals of its own node, through the same branch-free
@@ -810,11 +844,26 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
             uint64_t remaining = ballot(emits || fills);
             wave_sync();
             BVG_T1(0, tq0);
+            // WW: which of the lists with reference are built wave-wide
+            const bool wwn = wwon && emits && ref > 0 && d <= kWWBits && rlenS <= kWWBits && d >= (a.dbg >> 16);   // (bits 16.. of BVG_DBG: the shortest list built this way)
+            bool wwbad = false;
+            uint64_t wsum = 0;
             for (uint32_t L = 0; remaining; L++) {
-                const bool mem = emits && lvl == L, memf = fills && L == 0;
-                remaining &= ~ballot(mem || memf);
-                if (!ballot(mem || memf)) continue;
+                const bool memall = emits && lvl == L, memf = fills && L == 0;
+                const bool mem = memall && !wwn, memw = memall && wwn;
+                remaining &= ~ballot(memall || memf);
+                if (!ballot(memall || memf)) continue;
                 BVG_WC(0, 1);
+                if (ballot(mem || memf)) {
+                // ZE: a bit vector per member (one bit per element of the list being built + a clear word behind it), all zero before the extras pass
+                uint32_t ebase = 0; bool zel = false;
+                if (zeon) {
+                    const uint32_t ewn = mem ? ((d + 31u) >> 5) + 1u : 0u;
+                    const uint32_t eincl = wave_incl_scan32(ewn), etot = lane_get(eincl, 63);
+                    ebase = eincl - ewn;
+                    zel = etot != 0 && etot <= kZEWords;                      // (does not fit: this level keeps the position-by-position tasks)
+                    if (zel) { for (uint32_t w = lane; w < etot; w += 64) zem[w] = 0u; wave_sync(); }
+                }
                 // ---------------- Z1: one lane per extra: its output position = (extras below it) + (copied elements below it)
                 const uint32_t tq3 = BVG_T0();
                 {
@@ -843,10 +892,12 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         }
                         T vv = 0; uint32_t len = 1, pe = 0; bool isiv = false, isfill = false;
                         uint32_t f_k1 = 0;
-                        if (anyf) {                                           // (wave-uniform: the shuffles are executed by every lane)
+                        uint32_t t_eb = 0;
+                        if (anyf || zel) {                                    // (wave-uniform: the shuffles are executed by every lane)
                             const int s_f = __shfl((int)(memf ? 1 : 0), nl, 64);      // (hoisted: `tl && __shfl()` would run the shuffle under a lane mask)
                             isfill = tl && s_f != 0;
                             f_k1 = __shfl(k1, nl, 64);
+                            if (zel) t_eb = __shfl(ebase, nl, 64);
                         }
                         if (isfill) {                                         // an interval of a list decoded in place: its start was recorded when the residuals passed it
                             vv = scr[t_ib + 2 * q]; const T pk = scr[t_ib + 2 * q + 1];
@@ -880,8 +931,15 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         wave_sync();                                      // the parked values have been read: positions may replace them
                         if (tl && len) {
                             if (isfill) { for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); if (!MAT) fsum += mix_node<T>(f_k1, (T)(vv + i)); } }
+                            else if (isiv && zel) {                           // ZE: the interval is written here, element by element (LongIntervalSequenceIterator.java:71-78), and its places are marked
+                                for (uint32_t i = 0; i < len; i++) { pool[t_ob + pe + i] = (T)(vv + i); fsum += mix_node<T>(f_k1, (T)(vv + i)); atomicOr(&zem[t_eb + ((pe + i) >> 5)], 1u << ((pe + i) & 31u)); }
+                            }
                             else if (isiv) scr[t_ib + 2 * q + 1] = (T)len | (T)((T)pe << HS);
-                            else { if (MAT && t_gl) gp[pe] = (int64_t)((uint64_t)vv + nbase); else pool[t_ob + pe] = vv; rt[q - t_ic] = (T)pe; }
+                            else {
+                                if (MAT && t_gl) gp[pe] = (int64_t)((uint64_t)vv + nbase); else pool[t_ob + pe] = vv;
+                                rt[q - t_ic] = (T)pe;
+                                if (zel) atomicOr(&zem[t_eb + (pe >> 5)], 1u << (pe & 31u));
+                            }
                         }
                         wave_sync();
                     }
@@ -889,6 +947,61 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 }
                 BVG_T1(3, tq3);
                 const uint32_t tq1 = BVG_T0();
+                if (zel) {
+                // ---------------- Z2 by KEPT element (ZE): tasks of S consecutive kept elements of a member's referenced list (MaskedLongIterator.java:73-100), each written to
+                // the next clear bit of the member's bit vector -- the residuals and intervals are in place already (and summed), so no step is spent on their positions
+                const uint32_t ncl = mem ? (pure ? nres : ncopN) : 0u;
+                const uint32_t Wc = wave_sum32(ncl), Nc = (uint32_t)__popcll(ballot(ncl != 0));
+                uint32_t S = Nc < 64u ? (Wc + (63u - Nc)) / (64u - Nc) : 0x7FFFFFFFu;
+                if (S < kScanMinTask) S = kScanMinTask;
+                uint32_t Tn = 0;
+                if (ncl) { Tn = (uint32_t)((float)ncl / (float)S); while (Tn * S < ncl) Tn++; while (Tn > 1u && (Tn - 1u) * S >= ncl) Tn--; }
+                const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, Ttot = lane_get(tincl, 63);
+                uint64_t zsum = 0;
+                for (uint32_t p0 = 0; p0 < Ttot; p0 += 64) {
+                    const bool tl = p0 + lane < Ttot;
+                    BVG_WC(1, 1); BVG_WCL(2, tl ? 1u : 0u);
+                    const uint32_t own = deal_few(ballot(Tn != 0), tincl, ts, p0 + lane);
+                    const int nl = tl ? (int)own : (int)lane;
+                    const uint32_t s_first = (uint32_t)__shfl((int)ts, nl, 64);
+                    const uint32_t q = tl ? p0 + lane - s_first : 0u;
+                    const uint32_t t_nc = __shfl(ncl, nl, 64), t_rlb = __shfl(rlbN, nl, 64), t_rlen = __shfl(rlenS, nl, 64);
+                    const uint32_t t_bc = __shfl(bc, nl, 64), t_sb = __shfl(sb, nl, 64), t_ob = __shfl(base, nl, 64), t_k1 = __shfl(k1, nl, 64), t_eb = __shfl(ebase, nl, 64);
+                    const T* const rl = pool + t_rlb; T* const out = pool + t_ob; const uint32_t* const ew = zem + t_eb; const T* const blkp = scr + t_sb;
+                    uint32_t t = 0, tstop = 0, qcur = 0, krem = kInf, bi = t_bc, p = 0;
+                    if (tl) {
+                        t = q * S; tstop = t + S < t_nc ? t + S : t_nc;
+                        if (t_rlen) MaskPrefix<T>::select(blkp, t_bc, t_rlen, t, qcur, krem, bi);   // the t-th kept position of the referenced list
+                        // the t-th clear bit of the member's bit vector: whole words first, then inside the word
+                        uint32_t k = t, wi = 0, inv = ~ew[0];
+                        for (;;) { const uint32_t z = (uint32_t)__builtin_popcount(inv); if (k < z) break; k -= z; wi++; inv = ~ew[wi]; }   // (ends: the word behind the list is clear)
+                        uint32_t pos = 0;
+#pragma unroll
+                        for (uint32_t st = 16; st; st >>= 1) { const uint32_t c = (uint32_t)__builtin_popcount(inv & ((1u << (pos + st)) - 1u)); if (c <= k) pos += st; }
+                        p = (wi << 5) + pos;
+                    }
+                    const uint32_t rlast = t_rlen ? t_rlen - 1u : 0u;
+                    BVG_WCL(5, tstop - t); BVG_WC(4, wave_max32(tstop - t));
+                    for (; t < tstop; t++) {
+                        const T v = rl[qcur < rlast ? qcur : rlast];
+                        const T e0 = blkp[bi], e1 = blkp[bi + 1u];                        // (reads past the node's blocks stay inside the scratch area / the window)
+                        out[p] = v;
+                        zsum += mix_node<T>(t_k1, v);
+                        qcur++; krem--;
+                        const bool cross = krem == 0;                                     // the keep block ended: skip block bi, enter keep block bi + 1
+                        const uint32_t p0e = MaskPrefix<T>::pos(e0);
+                        const uint32_t nq = bi < t_bc ? p0e : t_rlen;
+                        const uint32_t nk = bi + 1u < t_bc ? MaskPrefix<T>::pos(e1) - p0e : kInf;
+                        qcur = cross ? nq : qcur; krem = cross ? nk : krem; bi += cross ? 2u : 0u;
+                        uint32_t pn = p + 1u;                                             // the next clear bit behind p
+                        uint32_t w = ~ew[pn >> 5] >> (pn & 31u);
+                        while (w == 0u) { pn = (pn | 31u) + 1u; w = ~ew[pn >> 5]; }
+                        p = pn + (uint32_t)__builtin_ctz(w);
+                    }
+                    wave_sync();
+                }
+                blk_chk += zsum;
+                } else {
                 // ---------------- Z2: tasks of S output positions, all equally long
                 // S in one step: sum_i ceil(d_i / S) <= W / S + N - N / S < 64 once S >= W / (64 - N)  (N lists, W positions in all)
                 const uint32_t Wl = wave_sum32(mem ? d : 0u), Nl = (uint32_t)__popcll(ballot(mem));
@@ -998,7 +1111,136 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                     wave_sync();
                     BVG_T1(4, tq4);
                 }
+                }   // (Z2 by position)
+                }   // (the position tasks: members that are not built wave-wide)
+                if (WWT && wwon) {
+                // ---------------- WW: the members of this level that are built WAVE-WIDE, one list after the other (their referenced lists are complete: they belong to
+                // an earlier level, sub-row or super-row).  Everything about a list is wave-uniform (read off its lane into scalar registers); the 64 lanes are 64
+                // consecutive positions.  (1) The copy mask (MaskedLongIterator.java:73-100) as a bit vector over the referenced list: every block end toggles one bit
+                // (lanes = blocks, ds_xor), an inclusive prefix-XOR of a 64-bit word on the scalar unit is the block-index parity of its 64 positions, kept = even; the
+                // kept elements are compacted to the FRONT of the list being built (rank = v_mbcnt under the mask).  (2) Extras: a lane per residual / interval finds
+                // how many kept elements lie below it (lower bound in the compacted front) -- its output position (MergedLongIterator.java:54-92 on disjoint streams)
+                // -- and sets that bit in the second bit vector.  (3) The kept elements are spread IN PLACE from the last 64 positions down to the first: position o
+                // holds front[o - (extras below o)] unless its bit is set; a set bit is the next residual (or an interval element, filled behind).  One multiply-add
+                // per copied / interval element; the residuals were summed when they were decoded.  No binary search per output position, no dealing, no levels inside.
+                uint64_t wm = ballot(memw);
+                while (wm) {
+                    const uint32_t j = (uint32_t)__ffsll((unsigned long long)wm) - 1u; wm &= wm - 1ull;
+                    const uint32_t n_d = lane_get(d, j), n_rlb = lane_get(rlbN, j), n_rlen = lane_get(rlenS, j), n_bc = lane_get(bc, j), n_sb = lane_get(sb, j);
+                    const uint32_t n_ic = lane_get(ic, j), n_ib = lane_get(ib, j), n_nres = lane_get(nresN, j), n_rtb = lane_get(rtbN, j), n_ob = lane_get(base, j), n_k1 = lane_get(k1, j);
+                    const T* const rl = pool + n_rlb; const T* const rt = pool + n_rtb; T* const out = pool + n_ob;
+                    // (1) copy mask -> bit vector -> compaction
+                    const uint32_t tw = (n_rlen + 63u) >> 6;
+                    if (lane < 2u * tw) wwm[lane] = 0u;
+                    wave_sync();
+                    for (uint32_t b0 = 0; b0 < n_bc; b0 += 64) {
+                        const uint32_t bi = b0 + lane;
+                        if (bi < n_bc) { const uint32_t eb = MaskPrefix<T>::pos(scr[n_sb + bi]); if (eb < n_rlen) atomicXor(&wwm[eb >> 5], 1u << (eb & 31u)); }
+                    }
+                    wave_sync();
+                    uint32_t kept = 0, carry = 0;
+                    for (uint32_t c = 0; c < tw; c++) {
+                        const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)wwm[2u * c]), thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)wwm[2u * c + 1u]);
+                        const uint64_t tg = ((uint64_t)thi << 32) | tlo;
+                        uint64_t x = tg; x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;    // bit p: parity of the block ends at or below position 64c + p
+                        if (carry) x = ~x;
+                        carry ^= (uint32_t)__popcll(tg) & 1u;
+                        uint64_t km = ~x;                                     // even block index: kept (behind the last block: kept iff their number is even -- the same parity)
+                        const uint32_t rem = n_rlen - 64u * c;
+                        if (rem < 64u) km &= (1ull << rem) - 1ull;
+                        if (__builtin_amdgcn_inverse_ballot_w64(km)) {
+                            const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                            out[kept + rk] = rl[64u * c + lane];
+                        }
+                        kept += (uint32_t)__popcll(km);
+                    }
+#ifdef BVG_WW_TRACE
+                    if (lane == 0) printf("WW node %lld d %u rlen %u bc %u kept %u nres %u ic %u\n", (long long)(r0 + j), n_d, n_rlen, n_bc, kept, n_nres, n_ic);
+#endif
+                    if (kept > n_d) { wwbad = true; break; }                  // (cannot happen in a validated block)
+                    // (2) the extras' positions -> second bit vector
+                    const uint32_t ew = (n_d + 63u) >> 6;
+                    wave_sync();
+                    if (lane < 2u * ew) wwm[lane] = 0u;
+                    wave_sync();
+                    const uint32_t fstep = kept ? 1u << (31u - (uint32_t)__builtin_clz(kept)) : 0u;      // branch-free lower bound in the front: the largest power of two <= kept
+                    auto front_lb = [&](T v) {                                // elements of the compacted front below v
+                        uint32_t lo = 0;
+                        for (uint32_t st = fstep; st; st >>= 1) { const uint32_t m = lo + st; if (m <= kept && out[m - 1u] < v) lo = m; }
+                        return lo;
+                    };
+                    if (n_ic) {
+                        const uint32_t rstep = n_nres ? 1u << (31u - (uint32_t)__builtin_clz(n_nres)) : 0u;
+                        for (uint32_t q0 = 0; q0 < n_ic; q0 += 64) {
+                            const uint32_t q = q0 + lane;
+                            if (q < n_ic) {
+                                const T leftv = scr[n_ib + 2u * q]; const uint32_t ln = (uint32_t)(scr[n_ib + 2u * q + 1u] & HM);
+                                uint32_t eb = 0;
+                                for (uint32_t k = 0; k < q; k++) eb += (uint32_t)(scr[n_ib + 2u * k + 1u] & HM);
+                                uint32_t lo = 0;
+                                for (uint32_t st = rstep; st; st >>= 1) { const uint32_t m = lo + st; if (m <= n_nres && rt[m - 1u] < leftv) lo = m; }
+                                const uint32_t pe = eb + lo + front_lb(leftv);
+                                if (pe + ln <= n_d) {
+                                    for (uint32_t i = 0; i < ln; i++) atomicOr(&wwm[(pe + i) >> 5], 1u << ((pe + i) & 31u));
+                                    scr[n_ib + 2u * q + 1u] = (T)ln | (T)((T)pe << HS);
+                                } else scr[n_ib + 2u * q + 1u] = (T)0;        // (cannot happen in a validated block; never write outside the list)
+                            }
+                        }
+                    }
+                    for (uint32_t i0 = 0; i0 < n_nres; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        if (i < n_nres) {
+                            const T e = rt[i];
+                            uint32_t pe = i + front_lb(e);
+                            for (uint32_t k = 0; k < n_ic; k++) { if (scr[n_ib + 2u * k] <= e) pe += (uint32_t)(scr[n_ib + 2u * k + 1u] & HM); }
+                            if (pe < n_d) atomicOr(&wwm[pe >> 5], 1u << (pe & 31u));
+                        }
+                    }
+                    wave_sync();
+                    // (3) spread the front over the list, from the top down
+                    uint32_t eabove = n_d - kept;                             // extras at or above the current chunk's first position
+                    for (uint32_t c = ew; c-- > 0u;) {
+                        const uint32_t elo = (uint32_t)__builtin_amdgcn_readfirstlane((int)wwm[2u * c]), ehi = (uint32_t)__builtin_amdgcn_readfirstlane((int)wwm[2u * c + 1u]);
+                        const uint64_t em = ((uint64_t)ehi << 32) | elo;
+                        const uint32_t ebelow = eabove - (uint32_t)__popcll(em);
+                        const uint32_t o = 64u * c + lane;
+                        const bool valid = o < n_d, isE = __builtin_amdgcn_inverse_ballot_w64(em);
+                        const uint32_t re = ebelow + __builtin_amdgcn_mbcnt_hi(ehi, __builtin_amdgcn_mbcnt_lo(elo, 0u));     // extras below position o
+                        const bool cpy = valid && !isE && re <= o;
+                        T v = 0;
+                        if (cpy) v = out[o - re];
+                        uint32_t ridx = re; bool isiv = false;
+                        for (uint32_t k = 0; k < n_ic; k++) {                 // (wave-uniform: the list's intervals)
+                            const T pk = scr[n_ib + 2u * k + 1u];
+                            const uint32_t ps = (uint32_t)(pk >> HS), ln = (uint32_t)(pk & HM);
+                            const uint32_t dd = o - ps;
+                            isiv = isiv || dd < ln;
+                            ridx -= o > ps ? (dd < ln ? dd : ln) : 0u;
+                        }
+                        const bool isR = valid && isE && !isiv && ridx < n_nres;
+                        T rv = 0;
+                        if (isR) rv = rt[ridx];
+                        wave_sync();                                          // every element of the chunk is read before any is written
+                        if (cpy) { out[o] = v; wsum += mix_node<T>(n_k1, v); }
+                        if (isR) out[o] = rv;
+                        wave_sync();
+                        eabove = ebelow;
+                    }
+                    // (4) the intervals (LongIntervalSequenceIterator.java:57-78): a lane each
+                    for (uint32_t q0 = 0; q0 < n_ic; q0 += 64) {
+                        const uint32_t q = q0 + lane;
+                        if (q < n_ic) {
+                            const T leftv = scr[n_ib + 2u * q]; const T pk = scr[n_ib + 2u * q + 1u];
+                            const uint32_t ps = (uint32_t)(pk >> HS), ln = (uint32_t)(pk & HM);
+                            for (uint32_t i = 0; i < ln; i++) { out[ps + i] = (T)(leftv + i); wsum += mix_node<T>(n_k1, (T)(leftv + i)); }
+                        }
+                    }
+                    wave_sync();
+                }
+                }
             }
+            blk_chk += wsum;
+            if (ballot(wwbad)) { failed = true; fail_need = 0xFFFFFFF5u; break; }
             // ---------------- leaf pass: the run queue, cut into chunks of kChunk elements dealt to all lanes.  Every referenced list
             // is complete by now.  A chunk is straight-line work: 4 elements per step, their LDS reads issued together.
             const uint32_t tqL = BVG_T0();
