@@ -135,6 +135,14 @@ template <typename T> inline T __shfl_xor(T v, int mask, int = 64) { return emu_
 template <typename T> inline T __shfl_up(T v, unsigned delta, int = 64) { const int l = (int)(threadIdx.x & 63u); return emu_lane_read(v, l >= (int)delta ? l - (int)delta : l); }
 template <typename T> inline T __shfl_down(T v, unsigned delta, int = 64) { const int l = (int)(threadIdx.x & 63u); return emu_lane_read(v, l + (int)delta < 64 ? l + (int)delta : l); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_lane_read(v, lane); }
+// ds_permute_b32 (forward permute): every lane sends `data` to lane (addr / 4) % 64; a lane nobody sends to reads 0, of several senders the highest lane wins
+inline int __builtin_amdgcn_ds_permute(int addr, int data) {
+    const uint64_t* all; emu::wave_gather(((uint64_t)(uint32_t)addr << 32) | (uint32_t)data, &all);
+    const unsigned l = threadIdx.x & 63u; int r = 0;
+    for (int j = 0; j < 64; j++) if ((((uint32_t)(all[j] >> 32)) >> 2 & 63u) == l) r = (int)(uint32_t)all[j];
+    emu::wave_release();
+    return r;
+}
 // v_mbcnt_lo / _hi: set bits of the mask word below this lane (+ add); inverse ballot: this lane's bit of a wave-uniform mask
 inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t m, uint32_t add) { const unsigned l = threadIdx.x & 63u; return add + (uint32_t)__builtin_popcount(l >= 32 ? m : (m & ((1u << l) - 1u))); }
 inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t m, uint32_t add) { const unsigned l = threadIdx.x & 63u; return add + (l > 32 ? (uint32_t)__builtin_popcount(m & ((1u << (l - 32)) - 1u)) : 0u); }

@@ -70,13 +70,23 @@ typedef uint32_t T;
 // prefix exceeds t.  Six shuffles find it (a binary search over the lanes) -- no map in LDS, no loop over a lane's tasks.  EVERY lane
 // must call it (a shuffle under a lane mask reads 0 from the masked lanes).
 __device__ __forceinline__ uint32_t task_owner(uint32_t incl, uint32_t t) {
+    // (round 6) a 4-ary search: three rounds of three INDEPENDENT shuffles (at a quarter, a half and three quarters of the span) instead of six dependent ones -- the
+    // same number of vector instructions, half the chain of LDS-crossbar round trips
     uint32_t lo = 0;
 #pragma unroll
-    for (uint32_t step = 32; step; step >>= 1) {
-        const uint32_t v = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), 64);
-        lo += v <= t ? step : 0u;
+    for (uint32_t step = 16; step; step >>= 2) {
+        const uint32_t v1 = (uint32_t)__shfl((int)incl, (int)(lo + step - 1), 64), v2 = (uint32_t)__shfl((int)incl, (int)(lo + 2 * step - 1), 64), v3 = (uint32_t)__shfl((int)incl, (int)(lo + 3 * step - 1), 64);
+        lo += (v1 <= t ? step : 0u) + (v2 <= t ? step : 0u) + (v3 <= t ? step : 0u);     // (the prefixes are non-decreasing: the three tests are a thermometer)
     }
     return lo < 64 ? lo : 63u;
+}
+// Where the k-th set bit of a lane mask is: every lane whose bit is set PUSHES its number to the lane of its rank (ds_permute: one trip through the crossbar); lane k then
+// holds the answer for k.  Lanes without a bit push to lane 63, which is read only when all 64 bits are set -- and then no such lane exists.  EVERY lane must call it.
+__device__ __forceinline__ uint32_t ranked_lanes(uint64_t m) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const bool mine = (m >> lane) & 1ull;
+    return (uint32_t)__builtin_amdgcn_ds_permute((int)((mine ? rk : 63u) << 2), (int)lane);
 }
 // The same when only a FEW lanes own tasks (the lists of one level of a sub-row: 4-8): a scalar loop over those lanes -- a v_readlane, a compare
 // and a select each -- instead of six dependent trips through the LDS crossbar.  `m` = lanes that own tasks, `first` = the tasks of the
@@ -133,8 +143,6 @@ __device__ __forceinline__ uint32_t select_bit(uint64_t m, uint32_t k) {
 template <bool Z3, bool WIDE, int OCC, bool D2, bool MAT>
 __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];     // pool | scratch | stream window
-    __shared__ uint16_t nd_base[kRing];           // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
-    __shared__ uint16_t nd_d[kRing];              // outdegree, clamped (a list longer than the pool fails the block before anything copies from it)
 
     const unsigned lane = threadIdx.x;
     const uint32_t wi = xcd_order(blockIdx.x, gridDim.x, a.xcds);                      // neighbouring blocks on one XCD (bvg_rows_common.h)
@@ -182,6 +190,10 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
     uint32_t* const wwm = reinterpret_cast<uint32_t*>(pool + CAP);
     uint32_t* const zem = reinterpret_cast<uint32_t*>(pool + CAP + (wwon ? kWWWords : 0u));
     uint32_t* const stage_w = reinterpret_cast<uint32_t*>(pool + CAPfull);   // the window over the stream: read by every sub-row of a super-row
+    // the node ring BEHIND the window, in the dynamic allocation (round 6): with no static LDS in front of it the dynamic area starts at LDS address 0, and the byte
+    // addresses the bit cursors of the hot loops compute need no base added
+    uint16_t* const nd_base = reinterpret_cast<uint16_t*>(stage_w + a.lds_stage_words);    // first pool element of a node's list (kNoList: a leaf, no list); pools hold < 65535 elements
+    uint16_t* const nd_d = nd_base + kRing;                                                // outdegree, clamped (a list longer than the pool fails the block before anything copies from it)
     const uint32_t* const stage = stage_w;
     const uint32_t stage_bits = a.lds_stage_words * 32u;
     const uint32_t sbitw = (uint32_t)(reinterpret_cast<const unsigned char*>(stage_w) - dyn_lds) << 3;   // the window's first bit, counted from the start of the dynamic LDS
@@ -326,8 +338,22 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         bool bad = false;
         uint64_t v;
         uint32_t d = 0;
+        // (round 6) the header fields from ONE 32-bit window each -- two dword reads and a funnel shift (the running bit address of bvg_scan_steps3.inc; at bit 0 of the
+        // window the shift is 0 and the dword in front of it, which is read along, drops out) -- and the 64-bit decoders only for a code of more than 31 bits
+        auto win_at = [&](uint32_t r) -> uint32_t {
+            const uint32_t tb0 = sbitw + r - 1u;
+            const uint32_t* const wp = reinterpret_cast<const uint32_t*>(dyn_lds + ((tb0 >> 3) & ~3u));
+            return __builtin_amdgcn_alignbit(wp[0], wp[1], ~tb0);
+        };
+        auto gamma_w32 = [&](uint32_t r, uint64_t& val) -> uint32_t {          // gamma: the length, 0 = does not fit 64 bits
+            const uint32_t w = win_at(r);
+            if (__builtin_expect(w < 0x10000u, 0)) return gamma64(win64<LIN>(stage, r), val);
+            const uint32_t len = 2u * (uint32_t)__builtin_clz(w) + 1u;
+            val = (w >> (32u - len)) - 1u;
+            return len;
+        };
         if (needed && lane < K1) {                                            // readOutdegree, BVG:654-660
-            const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
+            const uint32_t l = gamma_w32(rel, v);
             bad |= l == 0 || v > 0x7FFFFFFFull; rel += l; d = bad ? 0u : (uint32_t)v;
         }
         const uint32_t dclamp = d > CAP ? CAP + 1 : d;
@@ -346,15 +372,17 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
         // ---- A: reference and block count (BVG:1015-1021)
         if (parse) {
             if (W > 0) {                                                      // readReference, BVG:692-703
-                const uint64_t w = win64<LIN>(stage, rel);
-                const uint32_t lz = w ? (uint32_t)__builtin_clzll(w) : 64u; v = lz;
+                const uint32_t w3 = win_at(rel);
+                uint32_t lz = w3 ? (uint32_t)__builtin_clz(w3) : 32u;
+                if (__builtin_expect(w3 == 0u, 0)) { const uint64_t w = win64<LIN>(stage, rel); lz = w ? (uint32_t)__builtin_clzll(w) : 64u; }
+                v = lz;
                 const uint32_t l = lz < 64 ? lz + 1 : 0;
                 bad |= l == 0; rel += l;
                 if (v > W || (int64_t)v > x) { err |= ERR_REF_RANGE; v = 0; }
                 ref = (uint32_t)v;
             }
             if (ref > 0) {                                                    // readBlockCount, BVG:728-735
-                const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
+                const uint32_t l = gamma_w32(rel, v);
                 bad |= l == 0 || v > pend - rel + 1; rel += l; bc = bad ? 0u : (uint32_t)v;
             }
         }
@@ -440,7 +468,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 if (extra < 0) bad = true;
             }
             if (extra > 0 && minint != 0) {                                   // always gamma
-                const uint32_t l = gamma64(win64<LIN>(stage, rel), v);
+                const uint32_t l = gamma_w32(rel, v);
                 bad |= l == 0 || v > (pend - rel) / 2 + 1; rel += l; ic = bad ? 0u : (uint32_t)v;
             }
         }
@@ -683,6 +711,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                 const uint32_t tincl = wave_incl_scan32(Tn), ts = tincl - Tn, NL = lane_get(tincl, 63);
                 const uint64_t smask = ballot(shortt);
                 const uint32_t Ttot = NL + (uint32_t)__popcll(smask);
+                const uint32_t slanes = smask ? ranked_lanes(smask) : 0u;             // lane k: the k-th lane with a short tail (wave-uniform test: every lane takes part)
                 bool tbad = false;
                 // RU tasks per lane and pass, decoded in one interleaved loop: two independent chains per lane hide each other's LDS latency
                 auto task_passes = [&](auto RUc) {
@@ -702,12 +731,12 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
                         const bool isl = t < NL;
                         // (both searches are wave-uniformly skipped when this pass holds no task of their kind: the short tails sit in the last pass only)
                         const bool anylong = p0 + 64u * u < NL, anyshort = p0 + 64u * u + 63u >= NL && NL < Ttot;
-                        const uint32_t lown = anylong ? task_owner(tincl, isl ? t : 0u) : 0u, sown = anyshort ? select_bit(smask, (tl[u] && !isl) ? t - NL : 0u) : 0u;
+                        const uint32_t lown = anylong ? task_owner(tincl, isl ? t : 0u) : 0u, sown = anyshort ? (uint32_t)__shfl((int)slanes, (int)((tl[u] && !isl) ? t - NL : 0u), 64) : 0u;
                         const int nl = tl[u] ? (int)(isl ? lown : sown) : (int)lane;
-                        const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64), s_ce = (uint32_t)__shfl((int)ce, nl, 64);
-                        const uint32_t q = tl[u] ? (isl ? t - s_ts : s_ce) : 0u;
+                        const uint32_t s_ts = (uint32_t)__shfl((int)ts, nl, 64);
                         const uint32_t t_rel = __shfl(rel, nl, 64), t_rec = __shfl(recrel, nl, 64), t_pend = __shfl(pend, nl, 64);
                         const uint32_t t_nres = __shfl(nres, nl, 64), t_dst = __shfl(stored ? ((direct || d2) ? base : rtb) : (gl ? rtb : kInf), nl, 64), t_ef = __shfl(efirst, nl, 64);
+                        const uint32_t q = tl[u] ? (isl ? t - s_ts : (t_nres >= kSkipMin ? (t_nres - 1u) >> kSkipShift : 0u)) : 0u;     // a short tail is its node's last segment
                         const uint32_t s_k1 = __shfl(k1d, nl, 64);                 // (every lane takes part: a shuffle under a lane mask reads 0 from the masked lanes)
                         tk1[u] = tl[u] ? s_k1 : 0u;
                         const uint32_t t0 = q << kSkipShift;
@@ -1367,7 +1396,7 @@ __global__ void __launch_bounds__(64, OCC) scan_kernel(DecodeArgs a) {
 }  // namespace
 
 // what the kernel needs of LDS besides the pool and the scratch area (static arrays)
-size_t scan_static_lds() { return (size_t)kRing * 4; }
+size_t scan_static_lds() { return (size_t)kRing * 4; }   // (the node ring: part of the dynamic allocation since round 6, behind the window; the host's footprint sum is unchanged)
 
 template <int OCC, bool D2> static void launch_scan_occ(const DecodeArgs& a, uint32_t nblocks, bool wide, size_t dyn, hipStream_t s) {
     const bool z3 = a.cod.zeta_k == 3;
@@ -1383,7 +1412,7 @@ template <bool D2> static void launch_scan_mat(const DecodeArgs& a, uint32_t nbl
 
 void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, bool materialise, hipStream_t s) {
     if (nblocks == 0) return;
-    size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4;
+    size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4 + scan_static_lds();
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
     // D2 (lists without reference decoded in place around their intervals): only where such lists exist and are copied from
     const bool d2 = a.min_interval != 0 && a.window > 0 && !(knob("BVG_NO_D2") && atoi(knob("BVG_NO_D2")));
