@@ -180,11 +180,18 @@ def main():
                 share = os.path.join(sdir, "b")
                 leader = int(os.environ.get("LOCAL_RANK", rank)) == 0
                 try:
+                    lead_err = None
                     if leader:
-                        os.mkdir(sdir, 0o700)
-                        sts = generate(max(1, min(ncpu, 64)))             # the node's other ranks wait at the barrier: its leader may use every core
-                        save_stores(share, sts)
-                    dist.barrier()
+                        try:
+                            os.mkdir(sdir, 0o700)
+                            sts = generate(max(1, min(ncpu, 64)))         # the node's other ranks wait for the status below: its leader may use every core
+                            save_stores(share, sts)
+                        except Exception as ex:                           # (the other ranks must not sit in a barrier until the collective times out: they learn of it and raise too)
+                            lead_err = ex
+                    bad = torch.tensor([1 if lead_err is not None else 0], dtype=torch.int64, device=cuda if cuda is not None else "cpu")
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)            # doubles as the barrier behind the leader's work
+                    if int(bad.item()):
+                        raise RuntimeError("workload generation failed on a node's leader rank: %r" % (lead_err,))
                     if not leader:
                         sts = load_stores(share)
                     dist.barrier()
@@ -539,7 +546,17 @@ def real_graph_leg(W, torch, dev, threads, gib=4.0, steps=8):
     n0 = int(st.params.nodes)
     copies = max(1, min(int(gib * (1 << 30) / max(len(st.graph), 1)), ((1 << 31) - 1) // n0))
     base = W.BVGraph.from_memory(st.params, st.graph, st.offsets, device=dev)
-    g = W.mosaic([base], copies)
+    g = None
+    try:                                                                  # (the handles are closed whatever fails: a second 4 GiB graph must not outlive its leg)
+        g = W.mosaic([base], copies)
+        return _real_graph_scans(W, torch, g, st, n0, copies, threads, steps, O)
+    finally:
+        if g is not None:
+            g.close()
+        base.close()
+
+
+def _real_graph_scans(W, torch, g, st, n0, copies, threads, steps, O):
     n = g.num_nodes()
     r = g.scan()
     for _ in range(3):
@@ -556,7 +573,6 @@ def real_graph_leg(W, torch, dev, threads, gib=4.0, steps=8):
            "value": r["arcs"] / dt, "unit": "edges/s", "ms_per_step": dt * 1e3, "kernel_ms": kms / steps, "steps": steps, "nodes": n, "arcs": int(r["arcs"]),
            "graph_bytes": int(r["graph_bytes"]), "roofline_frac": r["graph_bytes"] / (kms / steps * 1e-3) / 1e9 / HBM_PEAK_GBS, "lean_blocks": int(r["lean_blocks"]),
            "gated": "tiles 0, %d, %d against the CPU oracle" % (copies // 2, copies - 1), "note": "same command as `python bench.py --shape cnr --target-gib 4`; not part of `value`"}
-    g.close(); base.close()
     return out
 
 

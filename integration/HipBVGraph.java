@@ -117,7 +117,8 @@ public final class HipBVGraph extends ImmutableGraph implements AutoCloseable {
 			succMem = nHostAlloc(8L * succCap); succ = succMem.order(ByteOrder.nativeOrder()).asLongBuffer();
 			cum = new long[nodes + 1];
 		}
-		void growSucc(final long needed) { nHostFree(succMem); succMem = nHostAlloc(8L * needed); succ = succMem.order(ByteOrder.nativeOrder()).asLongBuffer(); }
+		/** The new block first: if its allocation throws, the old one is still the one close() frees (exactly once). */
+		void growSucc(final long needed) { final ByteBuffer m = nHostAlloc(8L * needed); nHostFree(succMem); succMem = m; succ = succMem.order(ByteOrder.nativeOrder()).asLongBuffer(); }
 		void decode(final long from, final long to) {
 			long got;
 			while ((got = nDecodeRange(handle, from, to, deg, succ)) < 0) growSucc(-got);             // the size the library asked for (BVG_E_CAPACITY): nothing was written

@@ -70,11 +70,15 @@ JNIEXPORT jlongArray JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nInfo(JNI
 }
 JNIEXPORT void JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nOutdegrees(JNIEnv* e, jclass c, jlong h, jlong from, jlong to, jintArray out) {
     (void)c;
-    if ((*e)->GetArrayLength(e, out) < to - from) { throw_status(e, BVG_E_ARG); return; }
-    jint* d = (*e)->GetPrimitiveArrayCritical(e, out, 0);
-    if (!d) return;
-    const int st = bvg_outdegrees(H(h), from, to, (int32_t*)d);
-    (*e)->ReleasePrimitiveArrayCritical(e, out, d, 0);
+    if (to < from || (*e)->GetArrayLength(e, out) < to - from) { throw_status(e, BVG_E_ARG); return; }
+    /* bvg_outdegrees launches kernels and waits for a stream: never inside a JNI critical region (it would hold the collector, and every Java thread that needs it,
+       for the duration).  The degrees land in a page-locked block and are copied into the array afterwards. */
+    const jsize k = (jsize)(to - from);
+    int32_t* d = (int32_t*)bvg_host_alloc((size_t)(k > 0 ? k : 1) * sizeof(int32_t));
+    if (!d) { throw_status(e, BVG_E_NOMEM); return; }
+    const int st = bvg_outdegrees(H(h), from, to, d);
+    if (!st) (*e)->SetIntArrayRegion(e, out, 0, k, (const jint*)d);
+    bvg_host_free(d);
     if (st) throw_status(e, st);
 }
 /* direct (page-locked) buffers in, count out; -(needed) when the successor buffer is too small */
@@ -108,7 +112,9 @@ JNIEXPORT jobject JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nHostAlloc(J
     (void)c;
     void* p = bvg_host_alloc((size_t)(bytes > 0 ? bytes : 8));
     if (!p) { throw_status(e, BVG_E_NOMEM); return 0; }
-    return (*e)->NewDirectByteBuffer(e, p, bytes > 0 ? bytes : 8);
+    jobject b = (*e)->NewDirectByteBuffer(e, p, bytes > 0 ? bytes : 8);
+    if (!b) bvg_host_free(p);                                  /* (an OutOfMemoryError is pending: the pinned block must not leak) */
+    return b;
 }
 JNIEXPORT void JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nHostFree(JNIEnv* e, jclass c, jobject b) {
     (void)c;

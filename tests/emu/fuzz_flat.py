@@ -41,10 +41,10 @@ def main():
         dense = bool(rng.random() < 0.5)
         sub = dict(root=ROOT, kw=kw, n=int(rng.choice([5000, 7000, 9000])), seed=int(rng.integers(1, 1 << 20)), dense=dense, deg=float(rng.choice([30.0, 60.0, 120.0])),
                    piv=float(rng.choice([0.0, 0.3, 0.7])), maxd=int(rng.choice([300, 3000, 20000])))
-        env = dict(os.environ, BVG_HIP_LIB=os.path.join(HERE, "libbvgraph_emu.so"), BVG_TEST_KNOBS="1", BVG_FLAT=str(int(rng.random() < 0.7)), BVG_FLAT_RECS=str(int(rng.choice([64, 128, 256]))),
+        env = dict(os.environ, BVG_HIP_LIB=os.path.join(HERE, "libbvgraph_emu.so"), BVG_TEST_KNOBS="1", BVG_FLAT=str(int(rng.random() < 0.25)), BVG_FLAT_RECS=str(int(rng.choice([64, 128, 256]))),
                    BVG_EMU_ORDER=str(rng.choice(["fwd", "rev"])))
         # scan_kernel's list builds (BVG_DBG): 0 = position tasks, 8192 = ZE (kept-element tasks over the extras' bit vectors), 4096 = WW (experimental wave-wide build), both
-        lb = int(rng.choice([0, 8192, 8192, 4096, 12288])) if env["BVG_FLAT"] == "0" or os.environ.get("BVG_FUZZ_DBG") else 0
+        lb = int(rng.choice([0, 0, 0, 0, 8192, 4096, 12288])) if env["BVG_FLAT"] == "0" or os.environ.get("BVG_FUZZ_DBG") else 0
         if os.environ.get("BVG_FUZZ_DBG"):
             lb = int(os.environ["BVG_FUZZ_DBG"]); env["BVG_FLAT"] = "0"
         if lb:

@@ -82,3 +82,11 @@ def test_randomised_parity_of_the_lean_kernels_on_the_emulator(emu_lib):
 def test_dense_graph_through_the_emulated_kernels(emu_lib):
     out = run_case(6000, 5, "eu", 3)
     assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]
+
+
+@pytest.mark.parametrize("dbg,order", [(4096, "fwd"), (8192, "rev"), (12288, "fwd")])
+def test_round6_list_builds_on_the_emulator(emu_lib, dbg, order):
+    """scan_kernel's two round-6 experiments (compiled into the emulated and the experimental library only; both measured slower: csrc/bvg_scan.hip, "MEASURED") stay bit-exact:
+    WW (BVG_DBG=4096: stored lists with reference built wave-wide from lane bit vectors) and ZE (8192: position tasks by kept element over the extras' bit vectors)."""
+    out = run_case(6000, 5, "eu", 3, BVG_DBG=dbg, BVG_EMU_ORDER=order)
+    assert "emu case ok" in out and "lean_blocks 0 " not in out.splitlines()[2]
