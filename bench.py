@@ -333,6 +333,27 @@ def main():
         if dist is not None:
             no_index["s_per_step"] = S.allreduce_max(tn, device=cuda)
 
+    # ---- "marks only" (behind the timed region): what a consumer short of HBM gets -- a SECOND handle on the same synthetic stream (its own plan and index: an index belongs to
+    # its graph) with bvg_tuning.no_index = 2: the first scan validates and marks the blocks (the lean scan kernel takes them) but keeps entries only for lists of >= 4 096
+    # residuals: ~0.03 % of the stream instead of ~50 %.  Mosaic workloads on one rank only (the second graph takes another stream's worth of HBM for the leg).
+    marks = None
+    if not args.no_index_leg and world == 1 and sts and (copies > 1 or len(bases) > 1):
+        free1 = torch.cuda.mem_get_info(dev)[0]
+        gm = W.mosaic(bases, copies)
+        try:
+            gm.set_tuning(block_bits=args.block_bits, no_index=2); gm.set_node_base(g.node_base())
+            for _ in range(2):                                            # (validating pass = first scan; tier learning)
+                rm = gm.scan(lo, hi)
+            assert (rm["arcs"], rm["chk"]) == (int(r["arcs"]), int(r["chk"])), "the marks-only scan disagrees with the indexed one"
+            torch.cuda.synchronize(); tm0 = time.perf_counter()
+            for _ in range(3):
+                rm = gm.scan(lo, hi)
+            torch.cuda.synchronize(); tm = (time.perf_counter() - tm0) / 3
+            marks = {"s_per_step": tm, "lean_blocks": int(rm["lean_blocks"]), "index_entries": int(rm["index_entries"]), "index_bytes": int(rm["index_bytes"]),
+                     "resident": int(free1 - torch.cuda.mem_get_info(dev)[0])}
+        finally:
+            gm.close()
+
     # ---- the same scan at the reference's width (behind the timed region): BVGraph computes successors in `long`; the headline runs the 32-bit successor kernels, which is
     # lossless below 2^32 - 256 nodes (dtype "u32").  A flyweight with bvg_tuning.force_wide = 1 scans the same stream through the 64-bit-id path (its own skip index with
     # 64-bit values; the scan kernel on lists of ids relative to a per-block base, the checking kernels on 64-bit lists): same checksum, its own rate
@@ -406,6 +427,12 @@ def main():
                                "how": "bvg_copy() flyweight with bvg_tuning.no_index = 1: same stream, plan and offsets in HBM, no skip entries, no validation marks (every block on the checking kernels)"}
             gain = no_index["s_per_step"] - steady_s
             out["index_break_even_scans"] = (out["index_build_s"] / gain) if gain > 0 else None
+        if marks is not None:
+            out["value_marks_only"] = tot_arcs / marks["s_per_step"]
+            out["marks_only"] = {"ms_per_step": marks["s_per_step"] * 1e3, "steps": 3, "lean_blocks": marks["lean_blocks"], "index_entries": marks["index_entries"],
+                                 "index_bytes_per_launch": marks["index_bytes"], "hbm_resident_bytes": marks["resident"],
+                                 "how": "a second handle on the same stream with bvg_tuning.no_index = 2: validation marks (one byte per block) and skip entries for lists of >= 4 096 residuals only; "
+                                        "the lean scan kernel with one lane per residual list"}
         if wide is not None:
             out["value_wide"] = tot_arcs / wide["s_per_step"]
             out["wide"] = {"ms_per_step": wide["s_per_step"] * 1e3, "steps": 3, "dtype": "u64 ids (lists relative to a per-block base in the scan kernel; 64-bit lists on the checking kernels)",

@@ -270,7 +270,12 @@ typedef struct bvg_tuning {
     uint32_t reserved;       /* low byte 2 = experimental streaming kernel as tier 0; bits 8.. = its grab threshold */
     uint32_t no_index;       /* 1 = calls on THIS handle neither build nor read the residual skip index (nor the validation marks, so every
                                 block stays on the checking kernels): what a cold consumer gets from a graph it scans once; bench.py times
-                                a bvg_copy() flyweight with it (`value_no_index`) beside the indexed steady state (ABI version 3) */
+                                a bvg_copy() flyweight with it (`value_no_index`) beside the indexed steady state (ABI version 3).
+                                2 = "marks only" (round 6): the index THIS handle builds holds the validation marks (one byte per block of
+                                ~4 KiB of stream: the lean scan kernel takes the block) but entries only for lists of >= 4 096 residuals --
+                                ~0.03 % of the stream instead of ~50 %; the residuals of a list are then one lane's walk.  Measured
+                                (profiles/r06_ab_marks_*.txt): eu15 stand-in 113 G edges/s (indexed 310, checking kernels 45), cnr-2000
+                                tiled 142 (151, 80).  An index that exists already is used as it is. */
 } bvg_tuning;
 int bvg_set_tuning(bvg_graph* g, const bvg_tuning* t);
 

@@ -576,6 +576,7 @@ class BVGraph:
         return getattr(self, "_node_base", 0)
 
     def set_tuning(self, block_bits=0, force_wide=False, force_slow=False, stream=False, grab_threshold=0, legacy=False, no_index=False):
+        # (no_index: False / True, or 2 = "marks only": the index this handle builds keeps the validation marks and entries for lists of >= 4 096 residuals only)
         """stream=True selects the experimental streaming data-flow kernel (experimental/bvg_stream.hip) as tier 0; no_index=True makes
         this handle scan without the residual skip index (neither built nor read)."""
         t = Tuning(block_bits, int(force_wide), int(force_slow), (2 if stream else (1 if legacy else 0)) | (int(grab_threshold) << 8), int(no_index))

@@ -46,6 +46,9 @@ int build_skip(bvg_graph* g, const std::shared_ptr<Plan>& plp, uint32_t blo, uin
     std::shared_ptr<SkipIndex> ix = std::make_shared<SkipIndex>();
     ix->device = sh->device; ix->blk_lo = blo; ix->blk_hi = bhi; ix->wide = build_wide; ix->gen = next_plan_version();
     skip_granularity(sh, ix->skip_min, ix->skip_shift);
+    // bvg_tuning.no_index = 2 ("marks only", round 6): the validating pass and its marks -- one byte per block, what lets the lean scan kernel take the block -- but entries
+    // only for lists of 4 096 residuals and more (one per 64: the giant kernel's lists, which it cannot walk in step at any useful rate): an index of ~0.03 % of the stream
+    if (g->tun.no_index == 2) { ix->skip_min = 4096; ix->skip_shift = 6; }
     auto publish = [&]() { std::atomic_store(&pl.skip, ix); return 0; };
     // no index: the scans run without one.  The failure is PUBLISHED (an empty snapshot of the same block range, unless a good index of
     // other blocks exists already), so that later scans of these blocks do not pay the counting pass again and again; bvg_build_index() retries.

@@ -32,7 +32,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
     // The residual skip index is built the first time it would pay: a SCAN of >= 4096 nodes indexes the blocks it covers (a shard
     // of a multi-GPU scan builds its own part only; a later scan outside them indexes the whole graph), a materialising call
     // the whole graph once it covers a quarter of it.  bvg_build_index() does the same explicitly.
-    if (!batch && rows_default && g->skip_mode == 0 && !knob("BVG_NOSKIP") && !g->tun.no_index && (to - from) >= 4096 && nblocks) {
+    if (!batch && rows_default && g->skip_mode == 0 && !knob("BVG_NOSKIP") && g->tun.no_index != 1 && (to - from) >= 4096 && nblocks) {
         std::shared_ptr<SkipIndex> cur = std::atomic_load(&plp->skip);
         bool covered = cur && cur->covers(lo, lo + nblocks), retry = false;
         // a build that failed for want of memory is tried again every kRetryEvery-th scan of its blocks; so is the whole-graph rebuild behind a good partial index
@@ -50,7 +50,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         }
     }
     std::shared_ptr<SkipIndex> skx0 = g->skip_mode >= 2 ? g->skip_building : (g->skip_mode == 1 ? std::shared_ptr<SkipIndex>() : std::atomic_load(&plp->skip));
-    if (skx0 && g->skip_mode == 0 && (skx0->failed || g->tun.no_index)) skx0.reset();                // a failed build left no arrays; bvg_tuning.no_index: this handle scans without it
+    if (skx0 && g->skip_mode == 0 && (skx0->failed || g->tun.no_index == 1)) skx0.reset();                // a failed build left no arrays; bvg_tuning.no_index: this handle scans without it
     const std::shared_ptr<SkipIndex> skx = skx0;                                                       // held for the whole call
 
     if (nblocks > g->fail_cap) {                            // every block may fail over to the slow path
@@ -292,7 +292,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 const double lists = knob("BVG_SCAN_LISTS") ? atof(knob("BVG_SCAN_LISTS")) : 20.0;   // window lists + a sub-row's stored lists and parked residuals
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
-                for (uint64_t w : {24ull, 20ull, 16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
+                for (uint64_t w : {24ull, 20ull, 18ull, 16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
                     if (w > 16 && wforce != w && !(w == 24 && avg <= 16.0 && sh->p.window_size > 0 && !wforce && !materialise)) continue;   // more than 16: the 85-VGPR instantiation, sparse graphs with references only (web shape: +7 %; eu15: -11 % at 20; w0, all residuals: -6 %)
                     if (wforce && w != wforce && w != 4) continue;
                     uint64_t pw = 8192;
