@@ -111,7 +111,7 @@ void launch_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materi
 // the lean LDS-resident row kernel (bvg_rows.hip): tiers 0 and 1
 void launch_rows_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool materialise, hipStream_t s);
 // the lean scan kernel (bvg_scan.hip): validated blocks of a scan or (materialise) of a decode into a.succ, 32-bit lists, default codings, skip index present
-void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, bool materialise, hipStream_t s);
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, int occ, bool materialise, hipStream_t s);   // occ: 4 / 5 / 6 wavefronts per SIMD (128 / 96 / 80 VGPRs)
 size_t scan_static_lds();
 
 // the offsets index from a bare .graph in parallel (bvg_derive.hip): chunks of the stream walked speculatively, one code per lane and step, and iterated

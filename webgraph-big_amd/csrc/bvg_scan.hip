@@ -1410,7 +1410,7 @@ template <bool D2> static void launch_scan_mat(const DecodeArgs& a, uint32_t nbl
     else { if (z3) hipLaunchKernelGGL((scan_kernel<true, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); else hipLaunchKernelGGL((scan_kernel<false, false, 4, D2, true>), dim3(nblocks), dim3(64), dyn, s, a); }
 }
 
-void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool many_waves, bool materialise, hipStream_t s) {
+void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, int occ, bool materialise, hipStream_t s) {
     if (nblocks == 0) return;
     size_t dyn = (size_t)(a.lds_pool_elems + a.lds_scr_elems + a.lds_stage_words) * 4 + scan_static_lds();
     if (knob("BVG_SCAN_PAD")) dyn += (size_t)atoi(knob("BVG_SCAN_PAD"));   // occupancy experiments: unused LDS behind the window
@@ -1419,7 +1419,8 @@ void launch_scan_decode(const DecodeArgs& a, uint32_t nblocks, bool wide, bool m
     if (materialise) { if (d2) launch_scan_mat<true>(a, nblocks, wide, dyn, s); else launch_scan_mat<false>(a, nblocks, wide, dyn, s); }
     else if (knob("BVG_SCAN_OCC") && atoi(knob("BVG_SCAN_OCC")) == 5) { if (d2) launch_scan_occ<5, true>(a, nblocks, wide, dyn, s); else launch_scan_occ<5, false>(a, nblocks, wide, dyn, s); }   // experiments: 96 VGPRs, 20 wavefronts per CU
     else if (knob("BVG_SCAN_OCC") && atoi(knob("BVG_SCAN_OCC")) == 50) launch_scan_occ<5, false>(a, nblocks, wide, dyn, s);   // ... without the in-place decode around intervals (14 spills instead of 38)
-    else if (many_waves) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
+    else if (occ == 6) launch_scan_occ<6, false>(a, nblocks, wide, dyn, s);
+    else if (occ == 5) { if (d2) launch_scan_occ<5, true>(a, nblocks, wide, dyn, s); else launch_scan_occ<5, false>(a, nblocks, wide, dyn, s); }   // 18 / 20 wavefronts per CU
     else if (d2) launch_scan_occ<4, true>(a, nblocks, wide, dyn, s);
     else launch_scan_occ<4, false>(a, nblocks, wide, dyn, s);
 }

@@ -264,9 +264,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         uint32_t flat_recs = avg <= 16.0 ? 128u : 64u;
         if (knob("BVG_FLAT_RECS")) flat_recs = std::min(256u, std::max(64u, (unsigned)atoi(knob("BVG_FLAT_RECS")) & ~63u));
         const size_t lean_static = flat_on ? flat_table_bytes(flat_recs, sh->p.window_size) : scan_static_lds();
-        auto launch_lean = [&](DecodeArgs& al, uint32_t nb, bool many_waves, hipStream_t st) {
-            if (flat_on) { al.flat_recs = flat_recs; launch_flat_decode(al, nb, many_waves, st); }
-            else launch_scan_decode(al, nb, wide, many_waves, materialise, st);
+        auto launch_lean = [&](DecodeArgs& al, uint32_t nb, int occ, hipStream_t st) {                 // occ: wavefronts per SIMD the instantiation leaves registers for (4: 128 VGPRs, 5: 96, 6: 80)
+            if (flat_on) { al.flat_recs = flat_recs; launch_flat_decode(al, nb, occ == 6, st); }
+            else launch_scan_decode(al, nb, wide, occ, materialise, st);
         };
         DecodeArgs af = a;
         {
@@ -293,7 +293,9 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 uint64_t pool = 1024, waves = 4;
                 const uint64_t wforce = knob("BVG_SCAN_WAVES") ? strtoull(knob("BVG_SCAN_WAVES"), nullptr, 10) : 0;
                 for (uint64_t w : {24ull, 20ull, 18ull, 16ull, 14ull, 12ull, 10ull, 8ull, 6ull, 4ull}) {
-                    if (w > 16 && wforce != w && !(w == 24 && avg <= 16.0 && sh->p.window_size > 0 && !wforce && !materialise)) continue;   // more than 16: the 85-VGPR instantiation, sparse graphs with references only (web shape: +7 %; eu15: -11 % at 20; w0, all residuals: -6 %)
+                    // (round 6: 18 wavefronts -- the 96-VGPR instantiation, 4.5 per SIMD -- for graphs of 16 ... 48 arcs per node: uk +5.8 %, profiles/r06_ab_w18_*.txt; eu15, 86 arcs per node: -3 %)
+                    if (w > 16 && wforce != w && !(w == 24 && avg <= 16.0 && sh->p.window_size > 0 && !wforce && !materialise)
+                        && !(w == 18 && avg > 16.0 && avg <= 48.0 && sh->p.window_size > 0 && !wforce && !materialise && !knob("BVG_NO_W18"))) continue;   // more than 16: the 85-VGPR instantiation, sparse graphs with references only (web shape: +7 %; eu15: -11 % at 20; w0, all residuals: -6 %)
                     if (wforce && w != wforce && w != 4) continue;
                     uint64_t pw = 8192;
                     while (pw > 512 && lds_cu / foot(pw, w) < w) pw -= 32;
@@ -403,7 +405,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             const bool serial = knob("BVG_SERIAL") != nullptr;               // experiments: every launch alone on the chip (its own duration in a kernel trace)
             auto alone = [&](hipStream_t st) { if (serial) (void)hipStreamSynchronize(st); };
             if (tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
-            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_lean(a7, pd.count[7], lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), g->stream); launches++; alone(g->stream); }
+            if (tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_lean(a7, pd.count[7], lean_waves > 20 ? 6 : (lean_waves > 16 ? 5 : 4), g->stream); launches++; alone(g->stream); }
             if (ngiant && gbatch) {                                            // giants first: they are the critical path
                 DecodeArgs ag = a; ag.gpool = g->giant_ws; ag.gpool_elems = gpool_elems;
                 if (ag.skip_mode == 3) ag.skip_mode = 2;                              // (the giant kernel fills its own entries, in its own format, while it validates)
@@ -443,11 +445,11 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
                 ac.lds_pool_elems = lclasses[c - 1]; ac.lds_scr_elems = cscr[c - 1]; ac.lds_stage_words = cstage[c - 1];
                 if (knob("BVG_CLASS_STAGE")) { unsigned v[4] = {1024, 1024, 1024, 1024}; sscanf(knob("BVG_CLASS_STAGE"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_stage_words = std::min(2048u, std::max(128u, v[c - 1] & ~3u)); }   // experiments: the classes' LDS geometry
                 if (knob("BVG_CLASS_SCR")) { unsigned v[4] = {1024, 1024, 2048, 3072}; sscanf(knob("BVG_CLASS_SCR"), "%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3]); ac.lds_scr_elems = std::min(8192u, std::max(128u, v[c - 1])); }
-                launch_lean(ac, pd.count[7 + c], false, side_of(c)); alone(side_of(c));
+                launch_lean(ac, pd.count[7 + c], 4, side_of(c)); alone(side_of(c));
                 launches++;
             }
             if (t0_waits) HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[0], 0));
-            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_lean(a7, pd.count[7], lean_waves > 20 || (lean_waves > 16 && !knob("BVG_SCAN_OCC")), g->stream); launches++; alone(g->stream); }
+            if (!tier0_first && pd.count[7]) { DecodeArgs a7 = af; a7.work_list = pd.d_lists + offc[7]; launch_lean(a7, pd.count[7], lean_waves > 20 ? 6 : (lean_waves > 16 ? 5 : 4), g->stream); launches++; alone(g->stream); }
             if (!tier0_first && pd.count[0]) { launch_rows_any(a0, pd.count[0], g->stream); launches++; }
             for (int i = 0; i < bvg_graph::kSide; i++) { HIPCHK(hipEventRecord(g->side_ev[i], g->side[i])); HIPCHK(hipStreamWaitEvent(g->stream, g->side_ev[i], 0)); }
             HIPCHK(hipEventRecord(g->ev1, g->stream));
