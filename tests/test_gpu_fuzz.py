@@ -40,6 +40,7 @@ def _adjacency(rng, n):
 def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
     cases = int(os.environ.get("BVG_FUZZ", "16"))
     rng = np.random.default_rng(int(os.environ.get("BVG_FUZZ_SEED", "7")))
+    first = int(os.environ.get("BVG_FUZZ_FROM", "0"))
     for case in range(cases):
         for k in ("BVG_GIANT", "BVG_NOSKIP", "BVG_EMIT", "BVG_DBG"):
             monkeypatch.delenv(k, raising=False)
@@ -56,6 +57,11 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
         for k, v in env.items(): monkeypatch.setenv(k, v)
         off, adj = _adjacency(rng, n)
         p = W.default_params(**kw)
+        if case < first:                                                       # BVG_FUZZ_FROM=<case>: replay the generator up to a case (every draw below is made, nothing is run)
+            rng.random(); rng.integers(0, n + 1, 2); rng.integers(0, n, min(n, 40))
+            if n <= 6000 and adj.size: rng.random()
+            rng.choice([0, 64, 1000])
+            continue
         st = tools.store((off, adj), p, threads=2)
         g = W.BVGraph.from_memory(st.params, st.graph, st.offsets)
         wide = bool(rng.random() < 0.2)                                        # the 64-bit successor kernels on a small graph
@@ -64,7 +70,11 @@ def test_random_graphs_parameters_and_tiers(W, tools, oracle, monkeypatch):
         what = (case, n, kw, tier, env, wide)
         o = og.scan()
         for _ in range(2):                                                     # the second scan uses the index the first one built
-            r = g.scan()
+            try:
+                r = g.scan()
+            except Exception:
+                print("fuzz case that raised:", what, flush=True)
+                raise
             assert (r["nodes"], r["arcs"], r["chk"]) == (o["nodes"], o["arcs"], o["chk"]), what
         deg, succ = g.decode_range(0, n)
         assert np.array_equal(deg, np.diff(off.astype(np.int64))) and np.array_equal(succ, adj), what
