@@ -480,7 +480,11 @@ __global__ void __launch_bounds__(GNT, BVG_GIANT_MINWG) giant_kernel(DecodeArgs 
             ivtot = (uint32_t)before;
         }
         if (d > 0) nres = (uint32_t)extra;
-        if (wv == 0 && nres && !(sk_use && nres >= kSkipMin)) seek(cur);        // the residuals follow in step: wavefront 0's buffer goes back to the cursor
+        // the residuals follow in step unless index entries cut them into tasks: wavefront 0's buffer goes back to the cursor.  (Round 6, found by fuzz seed 601: the test was
+        // `nres >= kSkipMin`, but a list of EXACTLY kSkipMin residuals has no entry -- (nres - 1) >> shift == 0 -- and is decoded in step too: without the seek it read from wherever
+        // the header walk had left the buffer, and the self-check at the record's end refused the block on every scan after the index was built.)
+        const bool res_tasks = sk_use && nres >= kSkipMin && ((nres - 1u) >> kSkipShift) != 0u;
+        if (wv == 0 && nres && !res_tasks) seek(cur);
         const uint32_t cntE = nres >= kSkipMin ? (nres - 1u) >> kSkipShift : 0u;    // index entries of the residuals: 2 slots (+ a value) each
         const uint32_t efirst = sk_run;
         sk_run += 2u * cntE;
