@@ -66,6 +66,28 @@ constexpr uint32_t kChunk = BVG_SCAN_CHUNK;    // leaf elements per lane and pas
 
 typedef uint32_t T;
 
+#ifdef BVG_EXP_ZTAB
+// EXPERIMENT (-DBVG_EXP_ZTAB, see bvg_scan_steps3.inc): zeta_3 codes of up to 12 bits by their first 12 bits -> (value + 1) << 8 | length, 0 = longer; built at compile time
+struct Zeta3Tab { uint32_t e[4096]; };
+constexpr Zeta3Tab make_zeta3_tab() {
+    Zeta3Tab t{};
+    for (uint32_t p = 0; p < 4096; p++) {
+        uint32_t h = 0; while (h < 12 && !((p >> (11 - h)) & 1u)) h++;
+        uint32_t ent = 0;
+        if (h <= 2) {
+            const uint32_t nb = 3 * h + 3, len_long = h + 1 + nb;                         // the 3h + 3 bits behind the unary prefix
+            if (len_long <= 12) {
+                const uint32_t u = (p >> (12 - len_long)) & ((1u << nb) - 1u), thr = 1u << (3 * h + 1);
+                const bool sh = u < thr;
+                ent = ((sh ? (u + thr) >> 1 : u) << 8) | (len_long - (sh ? 1u : 0u));
+            }
+        }
+        t.e[p] = ent;
+    }
+    return t;
+}
+__device__ const Zeta3Tab kZeta3Tab = make_zeta3_tab();
+#endif
 // Dealing flat tasks to lanes: every lane holds the inclusive prefix `incl` of its own task count; task t belongs to the first lane whose
 // prefix exceeds t.  Six shuffles find it (a binary search over the lanes) -- no map in LDS, no loop over a lane's tasks.  EVERY lane
 // must call it (a shuffle under a lane mask reads 0 from the masked lanes).
