@@ -17,7 +17,7 @@ def _lists(x):
     # 40 residuals, long codes at even and odd indices (the skip index cuts at every 16th)
     v, l = x + 3, []
     for i in range(40):
-        l.append(v); v += (BIG + 5 * i) if i in (3, 8, 15, 16, 30, 31) else (HUGE if i == 21 else 2 + (i % 5))
+        l.append(v); v += (BIG + 5 * i) if i in (3, 8, 15, 16, 30, 31, 35) else (HUGE if i in (21, 37) else 2 + (i % 5))
     L.append(l)
     # first gap long and positive / negative (nat2int of a large value), then short gaps
     L.append([x + BIG * 3 + k * 3 for k in range(20)])
@@ -64,9 +64,13 @@ def test_oracle_decodes_the_long_codes(W, oracle):
 
 
 @pytest.mark.gpu
-def test_lean_kernel_takes_codes_of_32_bits_and_more(W, oracle):
+@pytest.mark.parametrize("no_index", [0, 2])
+def test_lean_kernel_takes_codes_of_32_bits_and_more(W, oracle, no_index):
+    """no_index = 2 (marks only): the lists of 40 residuals have no skip entries and are decoded by the whole wavefront behind their first 32 residuals (bvg_scan.hip, "COOP"):
+    the long codes at residuals 35 and 37 go through its 64-bit detour."""
     p, gb, offs, og, lists = _run(W, oracle, 500)                      # 5 000 nodes: the first scan builds the index, the later ones run the lean kernel
     hg = W.BVGraph.from_memory(p, gb, offs)
+    if no_index: hg.set_tuning(no_index=no_index)
     o = og.scan()
     for i in range(3):
         r = hg.scan()
