@@ -270,6 +270,16 @@ def main():
                 ro = ogs[j % K].scan(0, n0, node_base=nb + j * n0, threads=threads)
                 rg = g.scan(j * n0, (j + 1) * n0)
                 assert (rg["arcs"], rg["chk"]) == (ro["arcs"], ro["chk"]), "GPU scan of tile %d disagrees with the CPU oracle" % j
+            # ... and ONE gate that does not rest on the checksum (which is linear in the successors: two errors inside one node that cancel in their sum are invisible to it):
+            # the middle tile MATERIALISED through bvg_decode_range, every successor compared with the oracle's (BV coding is translation invariant: tile j = its base + j * n0)
+            if j_hi > j_lo and world == 1:                                # (one rank: the N > 1 path cannot be rehearsed on hardware here, and its gate stays what the rehearsals ran)
+                j = (j_lo + j_hi) // 2
+                gv = g.copy(); gv.set_tuning(block_bits=args.block_bits); gv.set_node_base(g.node_base())   # (a flyweight: what the timed handle has learned about its blocks -- per mode, scan or materialise -- stays untouched)
+                deg, succ = gv.decode_range(j * n0, (j + 1) * n0)
+                del gv
+                odeg, osucc = ogs[j % K].decode_range(0, n0)
+                assert np.array_equal(deg, odeg) and np.array_equal(succ, osucc + (nb + j * n0)), "materialised successors of tile %d disagree with the CPU oracle" % j
+                del deg, succ, odeg, osucc
             del ogs
         else:
             og = O.Graph.load(args.basename)

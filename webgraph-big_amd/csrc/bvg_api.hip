@@ -167,7 +167,7 @@ void bvg_close(bvg_graph* g) {
     if (g->slow_ws) (void)hipFree(g->slow_ws);
     if (g->giant_ws) (void)hipFree(g->giant_ws);
     if (g->d_gslots) (void)hipFree(g->d_gslots);
-    if (g->pred.d_lists) (void)hipFree(g->pred.d_lists);
+    for (auto& pd : g->pred2) if (pd.d_lists) (void)hipFree(pd.d_lists);
     for (int i = 0; i < bvg_graph::kSide; i++) { if (g->side[i]) { (void)hipStreamSynchronize(g->side[i]); (void)hipStreamDestroy(g->side[i]); } if (g->side_ev[i]) (void)hipEventDestroy(g->side_ev[i]); }
     release_shared(g->sh);
     delete g;

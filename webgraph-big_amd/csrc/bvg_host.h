@@ -166,7 +166,7 @@ struct bvg_graph {
     struct Pred {
         uint64_t plan_version = 0, skip_gen = 0; uint32_t lo = 0, n = 0, pool0 = 0, mode = 0; uint32_t* d_lists = nullptr; uint32_t count[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t giant_need = 0;
         std::vector<uint8_t> learned; std::vector<uint8_t> leanfail; uint64_t learned_version = 0, learned_gen = 0; uint32_t learned_pool0 = 0, learned_mode = 0; bool dirty = false;   // tier in which a mispredicted block finally succeeded: the next scans send it there directly
-    } pred;
+    } pred2[2];                                      // [0] scans, [1] materialising calls (round 6: a handle that alternates bvg_scan and bvg_decode_range keeps what it learned for each; one slot made every change of mode start from the prediction again)
 };
 
 namespace bvghost {

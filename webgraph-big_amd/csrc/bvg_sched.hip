@@ -152,7 +152,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         }
     }
     auto launch_rows_any = [&](const DecodeArgs& aa, uint32_t nb, hipStream_t st, bool is_class = false) {
-        if (flow && !is_class && aa.work_list == g->pred.d_lists) { launch_flow_scan(aa, nb, g->flow_waves, g->flow_ws, flow_ring, st); return; }
+        if (flow && !is_class && aa.work_list == g->pred2[materialise ? 1 : 0].d_lists) { launch_flow_scan(aa, nb, g->flow_waves, g->flow_ws, flow_ring, st); return; }
         const int nw = is_class && wg_class ? wg_class : wg_nw;
         if (nw) launch_rows_wg_decode(aa, nb, nw, st); else launch_rows_decode(aa, nb, wide, materialise, st);
     };
@@ -311,7 +311,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         }
         if (predict) {
             // blocks sorted into {tier 0, four LDS size classes, giants} by the largest list they hold
-            bvg_graph::Pred& pd = g->pred;
+            bvg_graph::Pred& pd = g->pred2[materialise ? 1 : 0];
             const uint32_t pool0 = a.lds_pool_elems;
             const uint32_t pmode = (materialise ? 1u : 0u) | (a.emit_tasks ? 2u : 0u) | (a.skip_first ? 4u : 0u) | (wide ? 8u : 0u) | (flow ? 16u : 0u) | (fast_ok ? 32u : 0u) | (fast_ok && flat_on ? 64u : 0u) | (fast_ok ? (af.lds_pool_elems << 8) : 0u);
             const uint64_t cap0 = flow ? 6144 : pool0;                          // the flow kernel keeps long lists in its scratch area
@@ -512,14 +512,14 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
             // what a class fails is tried in the next larger one (the need a block reported may come from another kernel's footprint)
             if (c < 3) bins[c + 1].insert(bins[c + 1].end(), again.begin(), again.end()); else rest.insert(rest.end(), again.begin(), again.end());
             if (predicted_run) {                               // remember where the survivors of this class fit
-                bvg_graph::Pred& pd = g->pred;
+                bvg_graph::Pred& pd = g->pred2[materialise ? 1 : 0];
                 std::sort(again.begin(), again.end());
                 for (uint32_t id : work)
                     if (id < pd.learned.size() && !std::binary_search(again.begin(), again.end(), id)) { pd.learned[id] = (uint8_t)(c + 1); pd.dirty = true; }
             }
         }
         work.swap(rest);
-        if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 5; pd.dirty = true; } }
+        if (predicted_run) { bvg_graph::Pred& pd = g->pred2[materialise ? 1 : 0]; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 5; pd.dirty = true; } }
     }
     // ---- tier 2a / 2: per-workgroup areas in global memory (kept in the handle), grown until every remaining block fits.  First the
     //      giant kernel (a workgroup per list); what it refuses (overlapping streams, contradictory counts) goes to the generic kernel.
@@ -568,7 +568,7 @@ int run_decode(bvg_graph* g, int64_t from, int64_t to, bool materialise, const u
         std::vector<uint32_t> refused;
         r = run_global_tier(true, refused); if (r) return r;
         work.swap(refused);
-        if (predicted_run) { bvg_graph::Pred& pd = g->pred; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 6; pd.dirty = true; } }
+        if (predicted_run) { bvg_graph::Pred& pd = g->pred2[materialise ? 1 : 0]; for (uint32_t id : work) if (id < pd.learned.size()) { pd.learned[id] = 6; pd.dirty = true; } }
     }
     { std::vector<uint32_t> none; r = run_global_tier(false, none); if (r) return r; }
     if (d_work) (void)hipFree(d_work);
