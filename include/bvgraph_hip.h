@@ -304,8 +304,8 @@ int bvg_abi_version(void);
  * odd), with probability ~2^-32 for a missing / surplus / misattributed one (32-bit keys; nodes
  * whose 32-bit hashes collide share a key).  Two errors inside ONE node that cancel in the sum of
  * its successors are invisible: the materialising parity tests (every successor against the oracle
- * / the golden) are the primary gate, this is the scan's self-check; bench.py --verify also decodes
- * tiles through bvg_decode_range, which does not rely on linearity.  (Rounds 1-4 used a non-linear
+ * / the golden) are the primary gate, this is the scan's self-check; bench.py's untimed gate also
+ * materialises one tile through bvg_decode_range: every successor against the oracle's.  (Rounds 1-4 used a non-linear
  * mix: six vector instructions per arc, a quarter of what a decoded successor has to cost.) */
 uint64_t bvg_arc_mix(uint64_t x, uint64_t y);
 
