@@ -48,7 +48,7 @@ public final class HipBVGraph extends ImmutableGraph implements AutoCloseable {
 	private static native long[] nBuildIndex(long h, long from, long to);                                          // bvg_build_index -> {entries, bytes}
 	private static native void nSaveIndex(long h, String path) throws IOException;                                 // bvg_save_index
 	private static native void nLoadIndex(long h, String path) throws IOException;                                 // bvg_load_index
-	private static native void nSetNoIndex(long h, boolean noIndex);                                               // bvg_set_tuning {no_index}
+	private static native void nSetIndexMode(long h, int mode);                                                    // bvg_set_tuning {no_index}: 0 full index, 1 none, 2 marks only
 
 	private HipBVGraph(final long h, final CharSequence basename, final int device) {
 		this.handle = h; this.basename = basename; this.device = device;
@@ -208,5 +208,8 @@ public final class HipBVGraph extends ImmutableGraph implements AutoCloseable {
 	public void saveIndex(final CharSequence path) throws IOException { ensureOpen(); nSaveIndex(handle, path.toString()); }      // basename + ".bvgidx": bvg_open picks it up (cf. the .obl file, BVGraph.java:1545-1555)
 	public void loadIndex(final CharSequence path) throws IOException { ensureOpen(); nLoadIndex(handle, path.toString()); }
 	/** A handle that scans a graph once should neither build nor read the index. */
-	public void setNoIndex(final boolean noIndex) { ensureOpen(); nSetNoIndex(handle, noIndex); }
+	public void setNoIndex(final boolean noIndex) { ensureOpen(); nSetIndexMode(handle, noIndex ? 1 : 0); }
+	/** How much index the scans of this handle build and use: {@code 0} the full residual skip index (~50 % of the stream in HBM), {@code 1} none (a graph scanned once),
+	 *  {@code 2} marks only (round 6: one byte per block + entries for lists of &ge; 4 096 residuals, ~0.03 % of the stream; ~36 % of the full index's rate on a dense web graph, 94 % on cnr-2000). */
+	public void setIndexMode(final int mode) { ensureOpen(); nSetIndexMode(handle, mode); }
 }

@@ -172,11 +172,13 @@ static void path_call(JNIEnv* e, jlong h, jstring path, int (*f)(bvg_graph*, con
 }
 JNIEXPORT void JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nSaveIndex(JNIEnv* e, jclass c, jlong h, jstring path) { (void)c; path_call(e, h, path, bvg_save_index); }
 JNIEXPORT void JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nLoadIndex(JNIEnv* e, jclass c, jlong h, jstring path) { (void)c; path_call(e, h, path, bvg_load_index); }
-JNIEXPORT void JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nSetNoIndex(JNIEnv* e, jclass c, jlong h, jboolean no_index) {
+/* mode: 0 = the full residual skip index, 1 = none (neither built nor read), 2 = marks only (validation marks + entries for lists of >= 4 096 residuals: bvg_tuning.no_index) */
+JNIEXPORT void JNICALL Java_it_unimi_dsi_big_webgraph_HipBVGraph_nSetIndexMode(JNIEnv* e, jclass c, jlong h, jint mode) {
     (void)c;
+    if (mode < 0 || mode > 2) { throw_status(e, BVG_E_ARG); return; }
     bvg_tuning t;
     memset(&t, 0, sizeof t);
-    t.no_index = no_index ? 1u : 0u;
+    t.no_index = (uint32_t)mode;
     const int st = bvg_set_tuning(H(h), &t);
     if (st) throw_status(e, st);
 }
