@@ -112,6 +112,9 @@ public:
         int32_t d; check(bvg_outdegrees(h_, x, x + 1, &d), "outdegree"); return d;
     }
     const bvg_params& params() const { return p_; }
+    // how much index the scans of this handle build and use (bvg_tuning.no_index): 0 = the full residual skip index, 1 = none, 2 = marks only (validation marks + entries for
+    // lists of >= 4 096 residuals: ~0.03 % of the stream instead of ~50 %)
+    void setIndexMode(int mode) { bvg_tuning t{}; t.no_index = (uint32_t)mode; check(bvg_set_tuning(h_, &t), "set_tuning"); }
     // BVGraph.store on the device (bvg_store; BVG:2404-2457 with chunkNodes > 0, the single-threaded store with 0): the bytes of
     // basename.graph and the bit offsets (basename.offsets holds their gamma-coded gaps)
     static void store(const bvg_params& p, const std::vector<uint64_t>& adjOff, const std::vector<int64_t>& adj, std::vector<uint8_t>& graph,
